@@ -1,0 +1,158 @@
+"""ctypes front-end for oracle/liboracle.so (TEST INFRASTRUCTURE: the checker)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORC = os.path.join(ROOT, "oracle")
+
+
+def _build():
+    so = os.path.join(_ORC, "liboracle.so")
+    src = [os.path.join(_ORC, f) for f in ("dory_oracle.c", "xavier_oracle.cpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.run(["make", "-C", _ORC, "liboracle.so"], check=True, capture_output=True)
+    return so
+
+
+lib = C.CDLL(_build())
+_f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32 = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+lib.orc_aggregate_gcn.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f, _f, _f]
+lib.orc_aggregate_gat_fwd.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f, _f]
+lib.orc_aggregate_gat_bwd.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f,
+                                      _u64, _u32, _f, _f, _f, _f]
+lib.orc_sgemm.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _f, _f, _f]
+lib.orc_sgemm_tn.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _f, _f, _f]
+lib.orc_tanh.argtypes = [C.c_size_t, _f, _f]
+lib.orc_tanh_backward.argtypes = [C.c_size_t, _f, _f, _f]
+lib.orc_softmax.argtypes = [C.c_uint32, C.c_uint32, _f, _f]
+lib.orc_train_stat.argtypes = [C.c_uint32, C.c_uint32, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+lib.orc_maskout.argtypes = [C.c_uint32, C.c_uint32, _f, _f]
+lib.orc_sub_scale.argtypes = [C.c_size_t, _f, _f, C.c_uint32, _f]
+lib.orc_vtx_forward_gcn_hidden.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _f, _f, _f, _f]
+lib.orc_vtx_forward_gcn_last.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f, _f, _f,
+                                         _f, _f, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+lib.orc_vtx_backward_gcn.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _f, _f, _f, _f, _f, _f, _f]
+lib.orc_edge_forward_gat.argtypes = [C.c_uint32, C.c_uint32, _u64, _f, _f, _f, _f]
+lib.orc_edge_backward_gat.argtypes = [C.c_uint32, C.c_uint32, _u64, _f, _f, _f, _f, _f, _f]
+lib.orc_adam_lr_t.argtypes = [C.c_float, C.c_uint]
+lib.orc_adam_lr_t.restype = C.c_float
+lib.orc_adam_update.argtypes = [C.c_size_t, C.c_float, _f, _f, _f, _f]
+lib.orc_xavier_init.argtypes = [C.c_uint, C.c_uint, _f]
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ghost(g, F):
+    return _c(g) if g is not None and g.size else np.zeros((1, F), np.float32)
+
+
+def aggregate_gcn(ptr, idx, val, norm, x, ghost=None):
+    x = _c(x)
+    N, F = x.shape
+    out = np.empty_like(x)
+    lib.orc_aggregate_gcn(N, F, _c(ptr, np.uint64), _c(idx, np.uint32), _c(val), _c(norm), x,
+                          _ghost(ghost, F), out)
+    return out
+
+
+def aggregate_gat_fwd(colptr, rowidx, A, z, zghost=None):
+    z = _c(z)
+    N, F = z.shape
+    out = np.empty_like(z)
+    lib.orc_aggregate_gat_fwd(N, F, _c(colptr, np.uint64), _c(rowidx, np.uint32), _c(A), z,
+                              _ghost(zghost, F), out)
+    return out
+
+
+def aggregate_gat_bwd(rowptr, colidx, AT, grad, gghost, colptr, rowidx, dA, z, zghost):
+    z = _c(z)
+    N, F = z.shape
+    out = np.empty_like(z)
+    lib.orc_aggregate_gat_bwd(N, F, _c(rowptr, np.uint64), _c(colidx, np.uint32), _c(AT), _c(grad),
+                              _ghost(gghost, F), _c(colptr, np.uint64), _c(rowidx, np.uint32),
+                              _c(dA), z, _ghost(zghost, F), out)
+    return out
+
+
+def sgemm(A, B, ta=False, tb=False):
+    A, B = _c(A), _c(B)
+    M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+    N = B.shape[0] if tb else B.shape[1]
+    Cm = np.empty((M, N), np.float32)
+    lib.orc_sgemm(int(ta), int(tb), M, N, K, A, B, Cm)
+    return Cm
+
+
+def vtx_forward_hidden(ah, W):
+    ah, W = _c(ah), _c(W)
+    N, Fin = ah.shape
+    Fout = W.shape[1]
+    z = np.empty((N, Fout), np.float32)
+    h = np.empty_like(z)
+    lib.orc_vtx_forward_gcn_hidden(N, Fin, Fout, ah, W, z, h)
+    return z, h
+
+
+def vtx_forward_last(ah, W, lab, globalV):
+    ah, W, lab = _c(ah), _c(W), _c(lab)
+    N, Fin = ah.shape
+    Cc = W.shape[1]
+    p = np.empty((N, Cc), np.float32)
+    d = np.empty_like(p)
+    grad = np.empty((N, Fin), np.float32)
+    dW = np.empty((Fin, Cc), np.float32)
+    acc, loss = C.c_float(), C.c_float()
+    lib.orc_vtx_forward_gcn_last(N, Fin, Cc, globalV, ah, W, lab, p, d, grad, dW, C.byref(acc), C.byref(loss))
+    return dict(p=p, d=d, grad=grad, dW=dW, acc=acc.value, loss=loss.value)
+
+
+def vtx_backward(aTg, z, ah, W, layer):
+    aTg, z, ah, W = _c(aTg), _c(z), _c(ah), _c(W)
+    N, Fout = z.shape
+    Fin = ah.shape[1]
+    g = np.empty_like(z)
+    dW = np.empty((Fin, Fout), np.float32)
+    grad = np.zeros((N, Fin), np.float32)
+    lib.orc_vtx_backward_gcn(N, Fin, Fout, layer, aTg, z, ah, W, g, dW, grad)
+    return g, dW, grad
+
+
+def edge_forward_gat(colptr, z, a):
+    z = _c(z)
+    N, F = z.shape
+    E = int(colptr[-1])
+    az = np.zeros(max(E, 1), np.float32)
+    A = np.zeros(max(E, 1), np.float32)
+    lib.orc_edge_forward_gat(N, F, _c(colptr, np.uint64), z, _c(a), az, A)
+    return az[:E], A[:E]
+
+
+def edge_backward_gat(colptr, grad, az, z, a):
+    z = _c(z)
+    N, F = z.shape
+    E = int(colptr[-1])
+    dA = np.zeros(max(E, 1), np.float32)
+    da = np.zeros(F, np.float32)
+    azp = np.zeros(max(E, 1), np.float32)
+    azp[:E] = az
+    lib.orc_edge_backward_gat(N, F, _c(colptr, np.uint64), _c(grad), azp, z, _c(a), dA, da)
+    return dA[:E], da
+
+
+def adam_update(w, grad, mom, dec, lr, epochs):
+    lr_t = lib.orc_adam_lr_t(lr, epochs)
+    lib.orc_adam_update(w.size, lr_t, w, _c(grad), mom, dec)
+    return lr_t
+
+
+def xavier(d1, d2):
+    w = np.empty((d1, d2), np.float32)
+    lib.orc_xavier_init(d1, d2, w)
+    return w

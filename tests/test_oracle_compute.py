@@ -1,0 +1,118 @@
+"""Oracle pin #2: the plain-C compute restatement (oracle/dory_oracle.c) agrees to
+1e-4 with the reference's Python GCN (miscs/numpy-gnn), through the fixture
+tests/golden/numpy_gnn_epoch.npz (made by oracle/gen_golden.py).  The adjacency
+fed to the C oracle comes from the partition oracle, itself pinned bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import partition_oracle as po
+
+RTOL = 1e-4  # BASELINE.json north_star: "within 1e-4 relative on fp32 activations"
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
+    V = int(z["V"])
+    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    return z, g
+
+
+def test_adjacency_matches_numpy_gnn(fx):
+    z, g = fx
+    N = g["localVtxCnt"]
+    A = np.zeros((N, N))
+    for v in range(N):
+        for e in range(int(g["colPtr"][v]), int(g["colPtr"][v + 1])):
+            A[v, g["rowIdx"][e]] += g["cscVal"][e]
+    A += np.diag(g["norm"])
+    assert rel_err(A, z["A_hat"]) < RTOL
+    # CSR is the transpose
+    AT = np.zeros((N, N))
+    for v in range(N):
+        for e in range(int(g["rowPtr"][v]), int(g["rowPtr"][v + 1])):
+            AT[v, g["colIdx"][e]] += g["csrVal"][e]
+    assert rel_err(AT + np.diag(g["norm"]), z["A_hat"].T) < RTOL
+
+
+def test_gcn_epoch_matches_numpy_gnn(fx):
+    z, g = fx
+    ah0 = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], z["X"])
+    assert rel_err(ah0, z["ah0"]) < RTOL
+    z0, h0 = orc.vtx_forward_hidden(ah0, z["W0"])
+    assert rel_err(z0, z["z0"]) < RTOL and rel_err(h0, z["h0"]) < RTOL
+    ah1 = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], h0)
+    assert rel_err(ah1, z["ah1"]) < RTOL
+    z1 = orc.sgemm(ah1, z["W1"])
+    assert rel_err(z1, z["z1"]) < RTOL
+    p = np.empty_like(z1)
+    orc.lib.orc_softmax(z1.shape[0], z1.shape[1], z1, p)
+    onehot = np.eye(z1.shape[1], dtype=np.float32)[z["labels"]]
+    d = p - onehot
+    assert rel_err(d, z["d"]) < RTOL
+    grad1 = orc.sgemm(d, z["W1"], tb=True)
+    assert rel_err(grad1, z["grad1"]) < RTOL
+    assert rel_err(orc.sgemm(ah1, d, ta=True), z["dW1"]) < RTOL
+    aTg0 = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], grad1)
+    assert rel_err(aTg0, z["aTg0"]) < RTOL
+    g0, dW0, _ = orc.vtx_backward(aTg0, z0, ah0, z["W0"], 0)
+    assert rel_err(g0, z["g0"]) < RTOL
+    assert rel_err(dW0, z["dW0"]) < RTOL
+
+
+def test_last_layer_sequence_and_quirks():
+    """vtxNNForwardGCN last-layer sequence incl. the maskout float-count quirk
+    (CPU_comm.cpp:464-471) -- checked against an independent numpy statement."""
+    rng = np.random.default_rng(3)
+    N, Fin, Cc, globalV = 50, 8, 5, 120
+    ah = rng.standard_normal((N, Fin)).astype(np.float32)
+    W = rng.standard_normal((Fin, Cc)).astype(np.float32)
+    lab = np.eye(Cc, dtype=np.float32)[rng.integers(0, Cc, N)]
+    r = orc.vtx_forward_last(ah, W, lab, globalV)
+    zz = ah.astype(np.float64) @ W
+    e = np.exp(zz - zz.max(1, keepdims=True))
+    p = e / e.sum(1, keepdims=True)
+    stt = int(N * 0.66)
+    val = range(stt, stt + int(N * 0.1))
+    acc = sum(lab[i, p[i].argmax()] for i in val)
+    loss = -sum(np.log(p[i, lab[i].argmax()]) for i in val)
+    assert abs(r["acc"] - acc) < 1e-6 and abs(r["loss"] - loss) < 1e-4 * max(1, abs(loss))
+    pm = p.copy().reshape(-1)
+    pm[stt * Cc: stt * Cc + (N - stt)] = lab.reshape(-1)[stt * Cc: stt * Cc + (N - stt)]
+    pm = pm.reshape(N, Cc)
+    d = (pm - lab) / (globalV * 0.66)
+    assert rel_err(r["d"], d) < RTOL
+    assert rel_err(r["grad"], d @ W.T.astype(np.float64)) < RTOL
+    assert rel_err(r["dW"], ah.T.astype(np.float64) @ d) < RTOL
+
+
+def test_adam_known_answer():
+    """One Adam step from w=.5, g=.1, lr=.01 (hand computation in float64)."""
+    w = np.full(4, 0.5, np.float32)
+    g = np.full(4, 0.1, np.float32)
+    m = np.zeros(4, np.float32)
+    v = np.zeros(4, np.float32)
+    orc.adam_update(w, g, m, v, 0.01, 1)
+    lr_t = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    mm, vv = 0.1 * 0.1, 0.001 * 0.01
+    expect = 0.5 - lr_t * mm / (np.sqrt(vv) + 1e-7)
+    assert abs(w[0] - expect) < 1e-6
+
+
+def test_xavier_stream_properties():
+    w = orc.xavier(602, 128)
+    lim = np.sqrt(6.0 / (602 + 128))
+    assert np.all(np.abs(w) <= lim * 1.0000001) and abs(w.mean()) < 1e-3
+    # minstd_rand0 first draw from seed 8888: x1 = 8888*16807 mod (2^31-1)
+    x1 = (8888 * 16807) % 2147483647
+    u = np.float32(np.float32(x1 - 1) / np.float32(2147483646.0))
+    assert abs(w[0, 0] - np.float32((2 * u - 1)) * np.float32(lim)) < 1e-6
