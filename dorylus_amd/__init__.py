@@ -1,0 +1,9 @@
+"""dorylus_amd -- MI355X-native aggregation + transform engine behind the
+reference's Engine / ResourceComm boundary (see include/dorylus_hip.h).
+
+Only the hot path lives here: HIP kernels + C-ABI (csrc/), the C++ host mirror of
+the reference's Engine stages and file formats (host/), and this thin ctypes layer.
+"""
+from ._lib import (BACKWARD, FORWARD, GAT, GCN, LIB_PATH, SYMBOLS, Context,  # noqa: F401
+                   DoryError, load)
+from .engine import Chunk, Engine  # noqa: F401

@@ -1,0 +1,264 @@
+"""ctypes binding of the C-ABI in include/dorylus_hip.h.
+
+There is no CPU fallback: a missing library or a missing gfx950 device raises.
+`import torch` (if the caller uses it) must happen before this module loads the
+library so that both share one HIP runtime (same SONAME libamdhip64.so.7).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdorylus_hip.so")
+
+# every symbol include/dorylus_hip.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "dory_create", "dory_destroy", "dory_last_error", "dory_set_streams", "dory_sync",
+    "dory_configure", "dory_graph_upload", "dory_preallocate", "dory_tensor_info",
+    "dory_tensor_upload", "dory_tensor_download", "dory_tensor_fill_uniform", "dory_labels_upload",
+    "dory_weight_set", "dory_weight_get", "dory_weight_grad_get", "dory_weights_init_xavier",
+    "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
+    "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
+    "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
+    "dory_timing_get", "dory_timing_reset", "dory_set_option",
+]
+
+FORWARD, BACKWARD = 0, 1
+GCN, GAT = 0, 1
+
+
+class DoryError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise DoryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+    cp = C.c_char_p
+    sig = {
+        "dory_create": [i32, C.POINTER(vp)],
+        "dory_destroy": [vp],
+        "dory_set_streams": [vp, vp, vp],
+        "dory_sync": [vp],
+        "dory_configure": [vp, i32, u32, vp, u32, u32, u32],
+        "dory_graph_upload": [vp, u32, u32, u32, u64, vp, vp, vp, u64, vp, vp, vp, vp],
+        "dory_preallocate": [vp],
+        "dory_tensor_info": [vp, u32, cp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(vp)],
+        "dory_tensor_upload": [vp, u32, cp, vp],
+        "dory_tensor_download": [vp, u32, cp, vp],
+        "dory_tensor_fill_uniform": [vp, u32, cp, u64, f32, f32, vp],
+        "dory_labels_upload": [vp, vp],
+        "dory_weight_set": [vp, u32, cp, vp],
+        "dory_weight_get": [vp, u32, cp, vp],
+        "dory_weight_grad_get": [vp, u32, cp, vp],
+        "dory_weights_init_xavier": [vp],
+        "dory_aggregate": [vp, u32, i32],
+        "dory_apply_vertex": [vp, u32, i32],
+        "dory_apply_edge": [vp, u32, i32],
+        "dory_predict_gat": [vp, u32],
+        "dory_train_stat": [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)],
+        "dory_halo_plan": [vp, i32, vp, vp, vp, vp],
+        "dory_comm_unique_id": [vp],
+        "dory_comm_init": [vp, vp, i32, i32],
+        "dory_halo_exchange": [vp, u32, i32],
+        "dory_halo_pack": [vp, u32, i32, vp],
+        "dory_halo_unpack": [vp, u32, i32, vp],
+        "dory_adam_config": [vp, f32],
+        "dory_weight_update": [vp, u32],
+        "dory_timing_enable": [vp, i32],
+        "dory_timing_get": [vp, cp, C.POINTER(C.c_double), C.POINTER(u64)],
+        "dory_timing_reset": [vp],
+        "dory_set_option": [vp, cp, C.c_int64],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    lib.dory_last_error.argtypes = [vp]
+    lib.dory_last_error.restype = cp
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU / one graph partition ("node" in the reference).  Thin, 1:1 with the C-ABI."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load()
+        h = C.c_void_p()
+        rc = self.lib.dory_create(device, C.byref(h))
+        if rc != 0:
+            raise DoryError(f"dory_create failed ({rc}): {self.lib.dory_last_error(None).decode()}")
+        self.h = h
+        self._keep = []
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise DoryError(f"dorylus_hip error {rc}: {self.lib.dory_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.dory_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- setup -----------------------------------------------------------------
+    def configure(self, gnn, dims, global_vtx_cnt, node_id=0, num_nodes=1):
+        d = np.ascontiguousarray(dims, dtype=np.uint32)
+        self.dims = [int(x) for x in d]
+        self.L = len(d) - 1
+        self._ck(self.lib.dory_configure(self.h, gnn, self.L, _ptr(d), global_vtx_cnt, node_id, num_nodes))
+
+    def graph_upload(self, g):
+        """g: dict with the fields of graph.<id>.bin."""
+        cp = np.ascontiguousarray(g["colPtr"], np.uint64)
+        ri = np.ascontiguousarray(g["rowIdx"], np.uint32)
+        cv = np.ascontiguousarray(g["cscVal"], np.float32)
+        rp = np.ascontiguousarray(g["rowPtr"], np.uint64)
+        ci = np.ascontiguousarray(g["colIdx"], np.uint32)
+        rv = np.ascontiguousarray(g["csrVal"], np.float32)
+        nm = np.ascontiguousarray(g["norm"], np.float32)
+        self.N = int(g["localVtxCnt"])
+        self._ck(self.lib.dory_graph_upload(
+            self.h, self.N, int(g["srcGhostCnt"]), int(g["dstGhostCnt"]), int(ri.size), _ptr(cp),
+            _ptr(ri), _ptr(cv), int(ci.size), _ptr(rp), _ptr(ci), _ptr(rv), _ptr(nm)))
+
+    def preallocate(self):
+        self._ck(self.lib.dory_preallocate(self.h))
+
+    # -- tensors ------------------------------------------------------------------
+    def info(self, layer, name):
+        rows, cols, ld, p = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_void_p()
+        self._ck(self.lib.dory_tensor_info(self.h, layer, name.encode(), C.byref(rows), C.byref(cols),
+                                           C.byref(ld), C.byref(p)))
+        return rows.value, cols.value, ld.value, p.value
+
+    def upload(self, layer, name, a):
+        rows, cols, _, _ = self.info(layer, name)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.size != rows * cols:
+            raise DoryError(f"upload {name}@{layer}: got {a.shape}, tensor is {rows}x{cols}")
+        self._ck(self.lib.dory_tensor_upload(self.h, layer, name.encode(), _ptr(a)))
+
+    def download(self, layer, name):
+        rows, cols, _, _ = self.info(layer, name)
+        a = np.empty((rows, cols), np.float32)
+        self._ck(self.lib.dory_tensor_download(self.h, layer, name.encode(), _ptr(a)))
+        return a
+
+    def fill_uniform(self, layer, name, seed, lo=-1.0, hi=1.0, row_ids=None):
+        ids = None if row_ids is None else np.ascontiguousarray(row_ids, np.uint32)
+        self._ck(self.lib.dory_tensor_fill_uniform(self.h, layer, name.encode(), seed, lo, hi, _ptr(ids)))
+
+    def labels_upload(self, labels):
+        l = np.ascontiguousarray(labels, np.uint32)
+        self._ck(self.lib.dory_labels_upload(self.h, _ptr(l)))
+
+    # -- weights ---------------------------------------------------------------------
+    def _wshape(self, layer, name):
+        return (self.dims[layer], self.dims[layer + 1]) if name == "w" else (self.dims[layer + 1], 1)
+
+    def weight_set(self, layer, name, w):
+        w = np.ascontiguousarray(w, np.float32)
+        assert w.size == int(np.prod(self._wshape(layer, name)))
+        self._ck(self.lib.dory_weight_set(self.h, layer, name.encode(), _ptr(w)))
+
+    def weight_get(self, layer, name="w"):
+        w = np.empty(self._wshape(layer, name), np.float32)
+        self._ck(self.lib.dory_weight_get(self.h, layer, name.encode(), _ptr(w)))
+        return w
+
+    def weight_grad_get(self, layer, name="w"):
+        w = np.empty(self._wshape(layer, name), np.float32)
+        self._ck(self.lib.dory_weight_grad_get(self.h, layer, name.encode(), _ptr(w)))
+        return w
+
+    def weights_init_xavier(self):
+        self._ck(self.lib.dory_weights_init_xavier(self.h))
+
+    # -- hot path ------------------------------------------------------------------------
+    def aggregate(self, layer, direction):
+        self._ck(self.lib.dory_aggregate(self.h, layer, direction))
+
+    def apply_vertex(self, layer, direction):
+        self._ck(self.lib.dory_apply_vertex(self.h, layer, direction))
+
+    def apply_edge(self, layer, direction):
+        self._ck(self.lib.dory_apply_edge(self.h, layer, direction))
+
+    def predict_gat(self, layer):
+        self._ck(self.lib.dory_predict_gat(self.h, layer))
+
+    def train_stat(self):
+        a, l, n = C.c_float(), C.c_float(), C.c_uint32()
+        self._ck(self.lib.dory_train_stat(self.h, C.byref(a), C.byref(l), C.byref(n)))
+        return a.value, l.value, n.value
+
+    # -- halo / comm ------------------------------------------------------------------------
+    def halo_plan(self, direction, send_lists, recv_slot_lists):
+        sc = np.array([len(x) for x in send_lists], np.uint32)
+        rc = np.array([len(x) for x in recv_slot_lists], np.uint32)
+        sl = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in send_lists] + [np.zeros(0, np.uint32)]), np.uint32)
+        rs = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in recv_slot_lists] + [np.zeros(0, np.uint32)]), np.uint32)
+        self._ck(self.lib.dory_halo_plan(self.h, direction, _ptr(sc), _ptr(sl), _ptr(rc), _ptr(rs)))
+
+    def comm_unique_id(self):
+        buf = np.zeros(128, np.uint8)
+        rc = self.lib.dory_comm_unique_id(_ptr(buf))
+        if rc != 0:
+            raise DoryError("ncclGetUniqueId failed")
+        return buf
+
+    def comm_init(self, id128, rank, nranks):
+        b = np.ascontiguousarray(id128, np.uint8)
+        self._ck(self.lib.dory_comm_init(self.h, _ptr(b), rank, nranks))
+
+    def halo_exchange(self, layer, direction):
+        self._ck(self.lib.dory_halo_exchange(self.h, layer, direction))
+
+    def halo_pack(self, layer, direction, dev_ptr):
+        self._ck(self.lib.dory_halo_pack(self.h, layer, direction, C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, layer, direction, dev_ptr):
+        self._ck(self.lib.dory_halo_unpack(self.h, layer, direction, C.c_void_p(dev_ptr)))
+
+    # -- optimiser ---------------------------------------------------------------------------
+    def adam_config(self, lr):
+        self._ck(self.lib.dory_adam_config(self.h, lr))
+
+    def weight_update(self, layer):
+        self._ck(self.lib.dory_weight_update(self.h, layer))
+
+    # -- misc -----------------------------------------------------------------------------------
+    def sync(self):
+        self._ck(self.lib.dory_sync(self.h))
+
+    def set_streams(self, compute=None, comm=None):
+        self._ck(self.lib.dory_set_streams(self.h, C.c_void_p(compute or 0), C.c_void_p(comm or 0)))
+
+    def timing_enable(self, on=True):
+        self._ck(self.lib.dory_timing_enable(self.h, int(on)))
+
+    def timing_get(self, family):
+        ms, n = C.c_double(), C.c_uint64()
+        self._ck(self.lib.dory_timing_get(self.h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def timing_reset(self):
+        self._ck(self.lib.dory_timing_reset(self.h))
+
+    def set_option(self, key, value):
+        self._ck(self.lib.dory_set_option(self.h, key.encode(), int(value)))

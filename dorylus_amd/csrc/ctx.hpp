@@ -1,0 +1,188 @@
+// ctx.hpp -- internal state behind the C-ABI (include/dorylus_hip.h).
+// MI355X / gfx950 only; no CUDA shims, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dorylus_hip.h"
+
+namespace dory {
+
+// Device tensor: row-major fp32, leading dimension padded to 32 floats (one
+// 128-B line) so that every row starts on a cache-line boundary and float4
+// lanes never straddle rows (602 -> 608).  Host layout stays dense.
+struct Tensor {
+    uint64_t rows = 0;
+    uint32_t cols = 0;
+    uint32_t ld = 0;
+    float *d = nullptr;
+    bool owned = true;  // false: alias of another allocation (GAT "A" = csc values)
+    size_t bytes() const { return (size_t)rows * ld * sizeof(float); }
+};
+
+inline uint32_t pad_ld(uint32_t cols) { return cols <= 1 ? cols : (cols + 31u) & ~31u; }
+
+struct Timing {
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+struct HaloPlan {
+    bool set = false;
+    std::vector<uint32_t> send_counts, recv_counts;  // per peer (rows)
+    std::vector<uint32_t> send_off, recv_off;        // prefix sums
+    uint32_t send_total = 0, recv_total = 0;
+    uint32_t *d_send_lvids = nullptr;  // concat over peers
+    uint32_t *d_recv_slots = nullptr;  // concat over peers
+};
+
+struct AdamState {
+    float lr = 0.01f;
+    unsigned epochs = 1;  // AdamOptimizer ctor calls nextIteration() once
+    float lr_t = 0.f;
+};
+
+}  // namespace dory
+
+struct dory_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    hipStream_t compute = nullptr, comm = nullptr;
+    bool own_compute = false, own_comm = false;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;  // cross-stream ordering
+
+    // model
+    bool configured = false;
+    int gnn = DORY_GCN;
+    uint32_t L = 0;
+    std::vector<uint32_t> dims;
+    uint32_t globalV = 0, nodeId = 0, numNodes = 1;
+
+    // graph (Graph, graph/graph.hpp:60-99)
+    bool has_graph = false;
+    uint32_t N = 0, Gsrc = 0, Gdst = 0;
+    uint64_t nnz_in = 0, nnz_out = 0;
+    uint64_t *colPtr = nullptr, *rowPtr = nullptr;
+    uint32_t *rowIdx = nullptr, *colIdx = nullptr;
+    float *cscVal = nullptr, *csrVal = nullptr, *norm = nullptr;
+    // longest-row-first schedules for the SpMM (built at upload)
+    uint32_t *orderIn = nullptr, *orderOut = nullptr;
+
+    // tensors / weights
+    bool prealloc = false;
+    std::vector<std::map<std::string, dory::Tensor>> tensors;   // [layer][name]
+    std::vector<std::map<std::string, dory::Tensor>> weights;   // "w", "a_i"
+    std::vector<std::map<std::string, dory::Tensor>> wgrads;    // same names
+    std::vector<std::map<std::string, dory::Tensor>> adam_m, adam_v;
+    dory::AdamState adam;
+
+    // scratch
+    float *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    float *d_stat = nullptr;  // [acc_sum, loss_sum]
+    uint32_t val_rows = 0;
+
+    // halo
+    dory::HaloPlan plan[2];
+    float *send_buf = nullptr, *recv_buf = nullptr;
+    size_t send_cap = 0, recv_cap = 0;
+    void *nccl = nullptr;  // ncclComm_t
+    int rank = 0, nranks = 1;
+
+    // options / timing
+    std::map<std::string, int64_t> opt;
+    bool timing = false;
+    std::map<std::string, dory::Timing> times;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct Pending { std::string fam; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+};
+
+namespace dory {
+
+// ---- kernel launchers (one translation unit per family) ---------------------
+// K1  CSR/CSC SpMM with fused self term:
+//   out[v,:] = self[v]*xl[v,:] + sum_e val[e] * row(idx[e])   (self = norm | 1 | none)
+struct SpmmArgs {
+    uint32_t N;             // rows (local vertices)
+    uint32_t F;             // logical feature width
+    uint32_t ld;            // leading dimension of xl, xg, out (all equal)
+    const uint64_t *ptr;    // N+1
+    const uint32_t *idx;    // nnz, local ids; >= N means ghost row idx-N
+    const float *val;       // nnz
+    const float *self_scale;// N or nullptr
+    int self_mode;          // 0: no self term, 1: self_scale[v]*xl[v], 2: 1*xl[v]
+    const float *xl;        // N x ld
+    const float *xg;        // G x ld (may be nullptr when no ghosts)
+    float *out;             // N x ld
+    int accumulate;         // 1: out += result (GAT backward second pass)
+    const uint32_t *order;  // optional row schedule (longest first) or nullptr
+};
+hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);
+
+// K2  fp32 MFMA GEMM  C = op(A) op(B) with fused epilogues
+enum GemmEpilogue { EPI_NONE = 0, EPI_TANH = 1 /* also writes tanh(C) to C2 */ };
+struct GemmArgs {
+    int ta, tb;             // op(A): M x K, op(B): K x N
+    uint32_t M, N, K;
+    const float *A; uint32_t lda;
+    const float *B; uint32_t ldb;
+    float *C; uint32_t ldc;
+    float *C2; uint32_t ldc2;   // EPI_TANH: h = tanh(z)
+    int epilogue;
+    // prologue on A (NN / TN only): A'[i,k] = A[i,k] * (1 - tanh(Zp[i,k])^2)
+    const float *Zp; uint32_t ldz;
+};
+hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s);
+size_t gemm_scratch_bytes(uint32_t M, uint32_t N);
+
+// K3/K4 elementwise + loss
+hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, uint32_t lda,
+                                const float *z, uint32_t ldz, float *g, uint32_t ldg, hipStream_t s);
+// softmax + validation stats + maskout quirk + (p - lab)/denom  (CPU_comm.cpp:108-122)
+hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
+                               const float *lab, uint32_t ldl, float *d, uint32_t ldd,
+                               float denom, uint32_t val_stt, uint32_t val_end,
+                               uint64_t mask_first, uint64_t mask_count, float *stat,
+                               hipStream_t s);
+// predictGAT: grad = softmax(z) - lab
+hipError_t launch_softmax_sub(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
+                              const float *lab, uint32_t ldl, float *out, uint32_t ldo, hipStream_t s);
+hipError_t launch_fill_uniform(float *d, uint64_t rows, uint32_t cols, uint32_t ld, uint64_t seed,
+                               float lo, float hi, hipStream_t s);
+hipError_t launch_fill_uniform_ids(float *d, uint64_t rows, uint32_t cols, uint32_t ld,
+                                   const uint32_t *row_ids, uint64_t seed, float lo, float hi,
+                                   hipStream_t s);
+hipError_t launch_onehot(float *d, uint64_t rows, uint32_t cols, uint32_t ld, const uint32_t *labels,
+                         hipStream_t s);
+hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t lds, uint64_t rows,
+                           uint32_t cols, hipStream_t s);
+
+// K5 GAT edge kernels
+hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,
+                                   uint32_t ldz, const float *a, float *az, float *A, hipStream_t s);
+hipError_t launch_edge_backward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *grad,
+                                    uint32_t ldg, const float *az, const float *a, float *dA,
+                                    float *cw /*N: deg(v)*dLRelu_v*/, hipStream_t s);
+hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *r, float *y,
+                         hipStream_t s);
+hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *w,
+                           float *partial, size_t partial_bytes, float *out, hipStream_t s);
+
+// K6 halo pack / unpack
+hipError_t launch_gather_rows(float *dst, const float *src, uint32_t ld, uint32_t cols,
+                              const uint32_t *rows, uint32_t n, hipStream_t s);
+hipError_t launch_scatter_rows(float *dst, const float *src, uint32_t ld, uint32_t cols,
+                               const uint32_t *rows, uint32_t n, hipStream_t s);
+
+// K7 Adam
+hipError_t launch_adam(float *w, const float *g, float *m, float *v, uint64_t n, float lr_t,
+                       hipStream_t s);
+
+}  // namespace dory

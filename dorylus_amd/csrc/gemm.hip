@@ -1,0 +1,213 @@
+// gemm.hip -- K2: fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32,
+// exact fp32 = a k-ordered fmaf chain), with the tanh epilogue (K3) fused.
+//
+// Replaces Matrix::dot -> cblas_sgemm (reference src/common/matrix.cpp:263-315) at
+// its call sites in CPUComm::vtxNN{Forward,Backward}{GCN,GAT}
+// (src/graph-server/commmanager/CPU_comm.cpp:98-188) and the cuBLAS path
+// CuMatrix::dot (GPU-Computation/cu_matrix.cu:205-232) + cudnnActivationForward
+// (comp_unit.cu:241-256).
+//
+// Shapes on this path are tall-skinny: M = |V_local| (2.3e5 .. 8e6), K,N <= 1433.
+//   NN  z    = ah * W          (+ h = tanh(z) epilogue)
+//   NT  grad = d  * W^T
+//   TN  dW   = ah^T * d        reduction over M: split-K over workgroups with a
+//                              deterministic second-stage sum (no atomics)
+// Tiling: 128 x BN block (BN = 128 or 64), BK = 32, 4 waves, each wave a
+// 64x64 (2x2 MFMA tiles) or 32x64 (1x2) register tile.  Both operands are staged
+// k-major in LDS (As[k][i], Bs[k][j]) so every fragment read is a conflict-free
+// ds_read_b32 of 32 consecutive floats per half-wave.
+#include "ctx.hpp"
+
+namespace dory {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+
+// Stage a (BK x BT) tile into LDS k-major.  kmajor source: elem(k,i) = p[k*ld+i];
+// otherwise elem(k,i) = p[i*ld+k] (transposing copy).
+template <int BT, bool KMAJOR, int LLD>
+__device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ p, uint32_t ld,
+                                           uint32_t ext, uint32_t Kend, uint32_t i0, uint32_t k0) {
+    const int t = threadIdx.x;
+    if constexpr (KMAJOR) {
+        constexpr int VPR = BT / 4;          // float4 per k-row
+        constexpr int KPI = 256 / VPR;       // k rows per iteration
+        const int i4 = (t % VPR) * 4;
+        for (int kk = t / VPR; kk < BK; kk += KPI) {
+            const uint32_t k = k0 + kk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < Kend) {
+                const float *src = p + (size_t)k * ld + i0 + i4;
+                if (i0 + i4 + 3 < ext) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (i0 + i4 + 0 < ext) v.x = src[0];
+                    if (i0 + i4 + 1 < ext) v.y = src[1];
+                    if (i0 + i4 + 2 < ext) v.z = src[2];
+                }
+            }
+            *reinterpret_cast<float4 *>(lds + kk * LLD + i4) = v;
+        }
+    } else {
+        constexpr int LPR = BK / 4;          // lanes per row (8)
+        constexpr int RPI = 256 / LPR;       // rows per iteration (32)
+        const int kq = (t % LPR) * 4;
+        for (int r = t / LPR; r < BT; r += RPI) {
+            const uint32_t i = i0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ext) {
+                const float *src = p + (size_t)i * ld + k0 + kq;
+                if (k0 + kq + 3 < Kend) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (k0 + kq + 0 < Kend) v.x = src[0];
+                    if (k0 + kq + 1 < Kend) v.y = src[1];
+                    if (k0 + kq + 2 < Kend) v.z = src[2];
+                }
+            }
+            lds[(kq + 0) * LLD + r] = v.x;
+            lds[(kq + 1) * LLD + r] = v.y;
+            lds[(kq + 2) * LLD + r] = v.z;
+            lds[(kq + 3) * LLD + r] = v.w;
+        }
+    }
+}
+
+template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
+    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 1;
+    constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 1;
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA_S + BK * LDB_S + 8];
+    float *As = smem;
+    float *Bs = smem + ((BK * LDA_S + 3) & ~3);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const uint32_t i0 = blockIdx.x * BM;
+    const uint32_t j0 = blockIdx.y * BN;
+    const uint32_t kbeg = blockIdx.z * klen;
+    const uint32_t kend = min(g.K, kbeg + klen);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int fr = lane & 31;   // row/col inside the 32-wide fragment
+    const int fk = lane >> 5;   // k offset inside the 2-deep MFMA
+    for (uint32_t k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        stage_tile<BM, A_KMAJOR, LDA_S>(As, g.A, g.lda, g.M, kend, i0, k0);
+        stage_tile<BN, B_KMAJOR, LDB_S>(Bs, g.B, g.ldb, g.N, kend, j0, k0);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = As[(kk + fk) * LDA_S + (wm * TM + a) * 32 + fr];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = Bs[(kk + fk) * LDB_S + (wn * TN + b) * 32 + fr];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool split = gridDim.z > 1;
+    float *C = split ? partial + (size_t)blockIdx.z * g.M * g.ldc : g.C;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const uint32_t col = j0 + (wn * TN + b) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = i0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < g.M && col < g.N) {
+                    const float v = acc[a][b][r];
+                    C[(size_t)row * g.ldc + col] = v;
+                    if (!split && g.epilogue == EPI_TANH)
+                        g.C2[(size_t)row * g.ldc2 + col] = tanhf(v);
+                }
+            }
+        }
+}
+
+// second stage of split-K: C = sum_z partial[z] in z order (deterministic)
+__global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M, uint32_t N,
+                                     uint32_t ldc, uint32_t S) {
+    const size_t n = (size_t)M * ldc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        if ((i % ldc) >= N) continue;
+        float s = 0.f;
+        for (uint32_t z = 0; z < S; ++z) s += partial[(size_t)z * n + i];
+        C[i] = s;
+    }
+}
+
+static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
+    const uint32_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    if (tiles >= 512 || K <= 4096) return 1;
+    uint32_t s = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+    const uint32_t maxs = (K + 4 * BK - 1) / (4 * BK);  // at least 4 k-tiles per split
+    if (s > maxs) s = maxs;
+    if (s > 512) s = 512;
+    return s < 1 ? 1 : s;
+}
+
+size_t gemm_scratch_bytes(uint32_t M, uint32_t N) {
+    // only split-K (small M x N, long K) uses scratch: 512 partials at most
+    const size_t mn = (size_t)M * pad_ld(N);
+    return mn <= (size_t)2048 * 2048 ? mn * 512 * sizeof(float) : 0;
+}
+
+template <int BN, int WM, int WN, int TM, int TN>
+static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
+    uint32_t S = pick_splits(g.M, g.N, g.K, BN);
+    if (S > 1 && (size_t)S * g.M * g.ldc * sizeof(float) > scratch_bytes) {
+        S = (uint32_t)(scratch_bytes / ((size_t)g.M * g.ldc * sizeof(float)));
+        if (S < 2) S = 1;
+    }
+    uint32_t klen = (g.K + S - 1) / S;
+    klen = (klen + BK - 1) / BK * BK;
+    S = (g.K + klen - 1) / klen;
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, S);
+    dim3 block(256);
+    if (!g.ta && !g.tb)
+        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, false, true>), grid, block, 0, s, g, klen, scratch);
+    else if (!g.ta && g.tb)
+        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, false, false>), grid, block, 0, s, g, klen, scratch);
+    else if (g.ta && !g.tb)
+        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, true, true>), grid, block, 0, s, g, klen, scratch);
+    else
+        return hipErrorInvalidValue;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (S > 1) {
+        const size_t n = (size_t)g.M * g.ldc;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.C, scratch, g.M, g.N, g.ldc, S);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
+    if (g.M == 0 || g.N == 0) return hipSuccess;
+    if (g.N > 64) return launch_bn<128, 2, 2, 2, 2>(g, scratch, scratch_bytes, s);
+    return launch_bn<64, 4, 1, 1, 2>(g, scratch, scratch_bytes, s);
+}
+
+}  // namespace dory

@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference Engine's synchronous epoch for the hot path.
+
+Same stage order, chunk state machine and entry-point names as the reference
+(src/graph-server/engine): scheduler -> GA (aggregate*) -> AV (applyVertex* ->
+ResourceComm::NNCompute) -> SC (scatter*) -> AE (applyEdge*) -> GA ...; in cpu/gpu
+mode there is exactly one chunk [0, N) per partition (engine/utils.cpp:598-609).
+Every stage is one C-ABI call; nothing here computes.
+"""
+from dataclasses import dataclass, replace
+
+from ._lib import BACKWARD, FORWARD, GAT, GCN, Context
+
+
+@dataclass
+class Chunk:
+    """common/utils.hpp:64-75"""
+    localId: int = 0
+    globalId: int = 0
+    lowBound: int = 0
+    upBound: int = 0
+    layer: int = 0
+    dir: int = FORWARD
+    epoch: int = 0
+    vertex: bool = True
+
+
+class Engine:
+    def __init__(self, ctx: Context, gnn: int, num_layers: int):
+        self.ctx = ctx
+        self.gnn_type = gnn
+        self.numLayers = num_layers
+        self.epoch_hook = None
+
+    # ---- layer utils (engine/utils.cpp:707-753) ------------------------------------
+    def incLayerGCN(self, c: Chunk) -> Chunk:
+        n = replace(c)
+        if n.dir == FORWARD:
+            n.layer += 1
+            if n.layer == self.numLayers:       # last forward layer merges into backward
+                n.dir = BACKWARD
+                n.layer -= 1
+        else:
+            if n.layer == 0:
+                n.dir = FORWARD
+                n.epoch += 1
+            else:
+                n.layer -= 1
+        return n
+
+    def incLayerGAT(self, c: Chunk) -> Chunk:
+        n = replace(c)
+        if n.dir == FORWARD:
+            n.layer += 1
+        else:
+            if n.layer == 0:
+                n.dir = FORWARD
+                n.vertex = True
+                n.epoch += 1
+            else:
+                n.layer -= 1
+        return n
+
+    def isLastLayer(self, c: Chunk) -> bool:
+        return c.dir == BACKWARD and c.layer == 0 and c.vertex
+
+    # ---- SAGA stages --------------------------------------------------------------------
+    def aggregateGCN(self, c):     # engine/ops/gcn_ops.cpp:130-191
+        self.ctx.aggregate(c.layer, c.dir)
+
+    def aggregateGAT(self, c):     # engine/ops/gat_ops.cpp:173-243
+        self.ctx.aggregate(c.layer, c.dir)
+
+    def NNCompute(self, c):        # ResourceComm::NNCompute (commmanager/CPU_comm.cpp:22-44)
+        if c.vertex:
+            self.ctx.apply_vertex(c.layer, c.dir)
+            # weight updates leave for the "weight server" right after the stage that
+            # produced them (CPU_comm.cpp:131,147): all-reduce + Adam on the device
+            if self.gnn_type == GCN:
+                if c.dir == BACKWARD or c.layer == self.numLayers - 1:
+                    self.ctx.weight_update(c.layer)
+            elif c.dir == BACKWARD:
+                self.ctx.weight_update(c.layer)
+        else:
+            self.ctx.apply_edge(c.layer, c.dir)
+
+    def applyVertexGCN(self, c):   # gcn_ops.cpp:194-202
+        c.vertex = True
+        if c.dir == FORWARD:
+            self.NNCompute(c)
+            return c
+        nxt = self.incLayerGCN(c)
+        self.NNCompute(nxt)
+        return nxt
+
+    def applyVertexGAT(self, c):   # gat_ops.cpp:267-275
+        c.vertex = True
+        if c.dir == FORWARD:
+            self.NNCompute(c)
+            return c
+        nxt = self.incLayerGAT(c)
+        self.NNCompute(nxt)
+        return nxt
+
+    def scatterGCN(self, c):       # gcn_ops.cpp:204-260 + ghostReceiverGCN :262-362
+        self.ctx.halo_exchange(c.layer, c.dir)
+
+    def scatterGAT(self, c):       # gat_ops.cpp:277-340
+        self.ctx.halo_exchange(c.layer, c.dir)
+
+    def applyEdgeGAT(self, c):     # gat_ops.cpp:437-440
+        c.vertex = False
+        self.NNCompute(c)
+
+    # ---- one synchronous epoch ------------------------------------------
+    def run_epoch(self, epoch=1):
+        N = getattr(self.ctx, "N", 0)
+        c = Chunk(0, 0, 0, N, 0, FORWARD, epoch, True)
+        if self.gnn_type == GCN:
+            while True:
+                self.aggregateGCN(c)                       # GA
+                c = self.applyVertexGCN(c)                 # AV (+ NNRecvCallbackGCN below)
+                if self.isLastLayer(c):
+                    break
+                if c.dir == FORWARD:
+                    c = self.incLayerGCN(c)                # resource_comm.cpp:44-46
+                self.scatterGCN(c)                         # SC
+                # AE: applyEdgeGCN is a no-op (gcn_ops.cpp:364-366)
+        else:
+            while True:
+                c.vertex = True
+                c = self.applyVertexGAT(c)                 # AV
+                if self.isLastLayer(c):
+                    break
+                if c.dir == FORWARD:
+                    c = self.incLayerGAT(c)                # resource_comm.cpp:81-83
+                self.scatterGAT(c)                         # SC
+                self.applyEdgeGAT(c)                       # AE
+                self.aggregateGAT(c)                       # GA
+                if c.dir == FORWARD and c.layer == self.numLayers:   # pipeline.cpp:203-213
+                    self.ctx.predict_gat(c.layer)
+                    c.dir = BACKWARD
+                    self.scatterGAT(c)
+                    self.applyEdgeGAT(c)
+                    self.aggregateGAT(c)
+        return self.incLayerGCN(c) if self.gnn_type == GCN else self.incLayerGAT(c)

@@ -1,0 +1,180 @@
+/*
+ * dorylus_hip.h -- C-ABI of the MI355X-native aggregation + transform engine.
+ *
+ * This is the drop-in boundary for the reference's "cpu"/"gpu" backends
+ * (uclasystem/dorylus, src/graph-server).  Every entry point replaces one piece
+ * of the reference's Engine / ResourceComm interface; the replaced code is cited
+ * as file:line relative to src/graph-server/ (or src/ where noted).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all functions return 0 on success or a
+ *     negative dory_status; dory_last_error() gives the message.  Nothing in the
+ *     library aborts the host process (the reference assert()/exit()s,
+ *     GPU-Computation/cu_matrix.cu:137-141).
+ *   - one dory_ctx per GPU / per graph partition ("node" in the reference).
+ *     Calls on one ctx are serialised internally (mutex), so they may come from
+ *     the Engine's different stage threads (engine/engine.cpp:243-273).
+ *   - all tensors are fp32 (FeatType/EdgeType = float, common/utils.hpp:28-29);
+ *     host buffers are dense row-major rows x cols exactly as the Engine's
+ *     savedNNTensors (engine/ops/gcn_ops.cpp:27-93); the device copy is
+ *     authoritative between dory_tensor_upload and dory_tensor_download.
+ *   - layer / dir arguments have the meaning of Chunk::layer / Chunk::dir
+ *     (common/utils.hpp:64-75) at the call site they replace.
+ */
+#ifndef DORYLUS_HIP_H
+#define DORYLUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dory_ctx dory_ctx;
+
+enum dory_status {
+    DORY_OK = 0,
+    DORY_ERR_ARG = -1,     /* bad argument / unknown tensor / wrong state        */
+    DORY_ERR_HIP = -2,     /* a HIP runtime call failed                          */
+    DORY_ERR_NODEVICE = -3,/* no usable MI355X (gfx950) device                   */
+    DORY_ERR_COMM = -4,    /* RCCL failure                                       */
+    DORY_ERR_IO = -5       /* file format / IO problem (host-side helpers)       */
+};
+
+enum dory_dir { DORY_FORWARD = 0, DORY_BACKWARD = 1 }; /* PROP_TYPE, common/utils.hpp:46 */
+enum dory_gnn { DORY_GCN = 0, DORY_GAT = 1 };          /* GNN,       common/utils.hpp:48 */
+
+/* ---- lifetime ---------------------------------------------------------------
+ * Replaces ComputingUnit::getInstance / ComputingServer construction
+ * (GPU-Computation/comp_unit.cu:23-46, engine/engine.cpp:141-163). */
+int dory_create(int device, dory_ctx **out);
+int dory_destroy(dory_ctx *ctx);
+const char *dory_last_error(dory_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* Adopt caller-owned HIP streams (hipStream_t passed as void*); NULL keeps the
+ * context's own.  compute: all kernels; comm: RCCL + pack/unpack. */
+int dory_set_streams(dory_ctx *ctx, void *compute_stream, void *comm_stream);
+int dory_sync(dory_ctx *ctx); /* wait for both streams (NodeManager::barrier's local half) */
+
+/* ---- model / partition description -------------------------------------------
+ * Replaces Engine::readLayerConfigFile + the Engine fields the backend reads
+ * (engine/utils.cpp:460-479; gnn_type, numLayers, layerConfig, nodeId, numNodes,
+ * graph.globalVtxCnt).  dims has num_layers+1 entries (run/reddit.config = 602 128 41). */
+int dory_configure(dory_ctx *ctx, int gnn_type, uint32_t num_layers,
+                   const uint32_t *dims, uint32_t global_vtx_cnt,
+                   uint32_t node_id, uint32_t num_nodes);
+
+/* Upload one partition's adjacency, exactly the arrays of Graph
+ * (graph/graph.hpp:60-99): forwardAdj (CSC over destination columns, in-edges)
+ * and backwardAdj (CSR over source rows, out-edges), 64-bit pointers, 32-bit
+ * local indices (ghost ids = N + k), per-edge values, vtxDataVec norms.
+ * Replaces the upload in Engine::init (engine/engine.cpp:105-125) and
+ * CuMatrix::loadSpCSR/loadSpCSC (GPU-Computation/cu_matrix.cu:36-98), without
+ * the 32-bit truncation of cu_matrix.cu:55-58. */
+int dory_graph_upload(dory_ctx *ctx, uint32_t local_vtx_cnt,
+                      uint32_t src_ghost_cnt, uint32_t dst_ghost_cnt,
+                      uint64_t nnz_in, const uint64_t *column_ptrs,
+                      const uint32_t *row_idxs, const float *csc_values,
+                      uint64_t nnz_out, const uint64_t *row_ptrs,
+                      const uint32_t *column_idxs, const float *csr_values,
+                      const float *vtx_norms);
+
+/* Allocate the named tensor table on the device: Engine::preallocateGCN /
+ * preallocateGAT (engine/ops/gcn_ops.cpp:27-93, gat_ops.cpp:27-115).  GCN names:
+ * x fg ah z h lab grad bg aTg; GAT names: h z az fg_z A ah grad dA aTg bg_d lab
+ * (SURVEY.md Appendix B).  Requires configure + graph_upload. */
+int dory_preallocate(dory_ctx *ctx);
+
+/* ---- named tensors (savedNNTensors[layer][name]) ----------------------------- */
+int dory_tensor_info(dory_ctx *ctx, uint32_t layer, const char *name,
+                     uint64_t *rows, uint32_t *cols, uint32_t *ld, void **device_ptr);
+/* host (dense rows x cols) -> device, and back; both synchronous w.r.t. the
+ * compute stream.  Replace the per-op cublasSetMatrix/GetMatrix round trips
+ * (cu_matrix.cu:101-120,149,173) with explicit, once-per-run transfers. */
+int dory_tensor_upload(dory_ctx *ctx, uint32_t layer, const char *name, const float *host);
+int dory_tensor_download(dory_ctx *ctx, uint32_t layer, const char *name, float *host);
+/* fill a tensor on the device (synthetic inputs): uniform[lo,hi) from a counter
+ * RNG keyed by (seed, global_row * cols + col).  global_row_ids (host, `rows`
+ * entries, or NULL for identity) makes a vertex's row independent of the
+ * partition that holds it (pass localToGlobalId / the ghost gvids). */
+int dory_tensor_fill_uniform(dory_ctx *ctx, uint32_t layer, const char *name,
+                             uint64_t seed, float lo, float hi,
+                             const uint32_t *global_row_ids);
+/* one-hot labels from u32 class ids (Engine::readLabelsFile, engine/utils.cpp:559-596) */
+int dory_labels_upload(dory_ctx *ctx, const uint32_t *labels);
+
+/* ---- weights (replaces MessageService weight fetch / push,
+ * commmanager/message_service.cpp:142-242, and the weight server's store) ------
+ * name is "w" (dims[l] x dims[l+1]) or "a_i" (dims[l+1] x 1, GAT). */
+int dory_weight_set(dory_ctx *ctx, uint32_t layer, const char *name, const float *host);
+int dory_weight_get(dory_ctx *ctx, uint32_t layer, const char *name, float *host);
+int dory_weight_grad_get(dory_ctx *ctx, uint32_t layer, const char *name, float *host);
+/* WeightServer::xavierInitializer, seed 8888 (src/weight-server/weightserver.cpp:567-585) */
+int dory_weights_init_xavier(dory_ctx *ctx);
+
+/* ---- the hot path ---------------------------------------------------------------
+ * dory_aggregate      = Engine::aggregateGCN / aggregateGAT (Chunk c) for the whole
+ *                       local partition [0, N)  (gcn_ops.cpp:130-191, gat_ops.cpp:173-243)
+ * dory_apply_vertex   = ResourceComm::NNCompute(chunk) with chunk.vertex == true
+ *                       (CPU_comm.cpp:22-44 -> vtxNNForward / vtxNNBackward, :98-188)
+ * dory_apply_edge     = NNCompute with chunk.vertex == false (CPU_comm.cpp:33-42 ->
+ *                       edgNNForwardGAT / edgNNBackwardGAT, :190-242); `layer` is the
+ *                       chunk's layer, the callee applies the reference's layer-1.
+ * dory_predict_gat    = Engine::predictGAT (gat_ops.cpp:246-265)
+ */
+int dory_aggregate(dory_ctx *ctx, uint32_t layer, int dir);
+int dory_apply_vertex(dory_ctx *ctx, uint32_t layer, int dir);
+int dory_apply_edge(dory_ctx *ctx, uint32_t layer, int dir);
+int dory_predict_gat(dory_ctx *ctx, uint32_t layer);
+
+/* validation accuracy / loss sums of the last forward pass
+ * (CPUComm::getTrainStat, CPU_comm.cpp:448-462; MessageService::sendAccloss) */
+int dory_train_stat(dory_ctx *ctx, float *acc_sum, float *loss_sum, uint32_t *val_rows);
+
+/* ---- ghost-vertex halo exchange (replaces Engine::scatterGCN/GAT +
+ * verticesPushOut + ghostReceiver*, gcn_ops.cpp:204-362, engine/utils.cpp:623-650)
+ * The plan is the per-peer send lists of graph.<id>.bin (forwardGhostsList /
+ * backwardGhostsList, graph/dataloader.cpp:277-297) plus, per peer, the ghost
+ * slots its rows land in (srcGhostVtcs / dstGhostVtcs order, dataloader.cpp:311-322).
+ * counts arrays have num_nodes entries; lists are concatenated in peer order. */
+int dory_halo_plan(dory_ctx *ctx, int dir, const uint32_t *send_counts,
+                   const uint32_t *send_lvids, const uint32_t *recv_counts,
+                   const uint32_t *recv_slots);
+/* RCCL communicator over xGMI: rank 0 makes an id (128 bytes), every rank passes
+ * the same bytes.  With num_nodes == 1 none of this is needed. */
+int dory_comm_unique_id(void *id128);
+int dory_comm_init(dory_ctx *ctx, const void *id128, int rank, int nranks);
+/* pack -> grouped ncclSend/ncclRecv (all-to-all-v) -> unpack into fg / bg
+ * (GCN: fwd sends h@(layer-1) into fg@layer, bwd sends grad@layer into bg@(layer-1);
+ *  GAT: fwd z@(layer-1) -> fg_z@(layer-1), bwd grad@(layer-1) -> bg_d@(layer-1);
+ *  `layer`/`dir` are the chunk's, as in Engine::scatter*).  */
+int dory_halo_exchange(dory_ctx *ctx, uint32_t layer, int dir);
+/* split entry points for callers that own the transport (tests, other MPI):
+ * buffers are device pointers of total_send_rows x cols / total_recv_rows x cols */
+int dory_halo_pack(dory_ctx *ctx, uint32_t layer, int dir, float *send_buf);
+int dory_halo_unpack(dory_ctx *ctx, uint32_t layer, int dir, const float *recv_buf);
+
+/* ---- weight-gradient reduction + optimiser (replaces the weight server's
+ * PUB/SUB all-gather-and-sum + Adam, src/weight-server/weightserver.cpp:89-187,
+ * weighttensor.cpp:131-166,246-328, AdamOptimizer.cpp:29-51) ---------------------
+ * dory_weight_update: all-reduce(sum) of the layer's gradient over the
+ * communicator (no-op when alone), then one Adam step.  Layer 0 advances the
+ * optimiser's iteration count like AdamOptimizer::update. */
+int dory_adam_config(dory_ctx *ctx, float learning_rate);
+int dory_weight_update(dory_ctx *ctx, uint32_t layer);
+
+/* ---- introspection -------------------------------------------------------------- */
+/* average device time (ms) and launch count of a kernel family since the last
+ * reset, measured with HIP events on the stream the kernel runs on; names:
+ * "spmm", "gemm", "loss", "edge", "halo", "adam". */
+int dory_timing_enable(dory_ctx *ctx, int on);
+int dory_timing_get(dory_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
+int dory_timing_reset(dory_ctx *ctx);
+/* tuning knobs (e.g. "spmm_variant", "spmm_slab"); unknown keys are an error */
+int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DORYLUS_HIP_H */

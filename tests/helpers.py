@@ -1,0 +1,113 @@
+"""Shared test helpers: oracle-side epoch (CPU, via oracle/) and context setup."""
+import numpy as np
+
+import orc
+import partition_oracle as po
+
+
+def splitmix_uniform(seed, rows_global, cols, lo=-1.0, hi=1.0):
+    """numpy twin of the device counter RNG (csrc/elementwise.hip fill_uniform_kernel)."""
+    rows_global = np.asarray(rows_global, dtype=np.uint64)
+    idx = rows_global[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) ^ idx) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (np.float32(lo) + (np.float32(hi) - np.float32(lo)) * u).astype(np.float32)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def random_graph(seed, V, E, symmetric=True):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, V, E)
+    d = rng.integers(0, V, E)
+    if symmetric:
+        s, d = np.concatenate([s, d]), np.concatenate([d, s])
+    return s.astype(np.uint32), d.astype(np.uint32)
+
+
+def partitions(src, dst, parts, P, undirected=False):
+    return [po.preprocess(src, dst, parts, r, P, undirected) for r in range(P)]
+
+
+def oracle_gcn_epoch(gs, parts, X, labels, Ws, globalV):
+    """One synchronous GCN epoch over P in-process partitions with the C oracle;
+    the ghost exchange is the semantic oracle of SURVEY.md 8c (fg[slot(gvid)] =
+    owner.h[lvid(gvid)]).  Returns per-partition tensor dicts and summed dW."""
+    P = len(gs)
+    L = len(Ws)
+    g2owner = np.asarray(parts)
+    g2l = {}
+    for r, g in enumerate(gs):
+        for l, gv in enumerate(g["localToGlobal"]):
+            g2l[int(gv)] = (r, l)
+
+    def ghosts(key, tensors):
+        out = []
+        for r, g in enumerate(gs):
+            rows = [tensors[g2l[int(gv)][0]][g2l[int(gv)][1]] for gv in g[key]]
+            F = tensors[0].shape[1]
+            out.append(np.asarray(rows, np.float32).reshape(len(rows), F))
+        return out
+
+    T = [dict() for _ in range(P)]
+    h = [X[g["localToGlobal"]] for g in gs]
+    for r in range(P):
+        T[r]["x"] = h[r]
+    for l in range(L):
+        fg = ghosts("srcGhost", h)
+        for r, g in enumerate(gs):
+            T[r][f"fg{l}"] = fg[r]
+            T[r][f"ah{l}"] = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], h[r], fg[r])
+        if l < L - 1:
+            nh = []
+            for r in range(P):
+                z, hh = orc.vtx_forward_hidden(T[r][f"ah{l}"], Ws[l])
+                T[r][f"z{l}"], T[r][f"h{l}"] = z, hh
+                nh.append(hh)
+            h = nh
+    dW = [None] * L
+    C = Ws[-1].shape[1]
+    grads = []
+    acc = loss = 0.0
+    for r, g in enumerate(gs):
+        lab = np.eye(C, dtype=np.float32)[labels[g["localToGlobal"]]]
+        T[r]["lab"] = lab
+        res = orc.vtx_forward_last(T[r][f"ah{L-1}"], Ws[L - 1], lab, globalV)
+        T[r][f"grad{L-1}"] = res["grad"]
+        T[r]["d"] = res["d"]
+        T[r]["acc"], T[r]["loss"] = res["acc"], res["loss"]
+        dW[L - 1] = res["dW"] if dW[L - 1] is None else dW[L - 1] + res["dW"]
+        grads.append(res["grad"])
+    for l in range(L - 1, 0, -1):
+        bg = ghosts("dstGhost", grads)
+        ngr = []
+        for r, g in enumerate(gs):
+            T[r][f"bg{l-1}"] = bg[r]
+            aTg = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], grads[r], bg[r])
+            T[r][f"aTg{l-1}"] = aTg
+            gg, dw, gr = orc.vtx_backward(aTg, T[r][f"z{l-1}"], T[r][f"ah{l-1}"], Ws[l - 1], l - 1)
+            T[r][f"g{l-1}"] = gg
+            if l - 1 > 0:
+                T[r][f"grad{l-1}"] = gr
+            dW[l - 1] = dw if dW[l - 1] is None else dW[l - 1] + dw
+            ngr.append(gr)
+        grads = ngr
+    return T, dW
+
+
+def make_ctx(da, g, dims, globalV, gnn=0, node_id=0, num_nodes=1, device=0):
+    ctx = da.Context(device)
+    ctx.configure(gnn, dims, globalV, node_id, num_nodes)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    return ctx

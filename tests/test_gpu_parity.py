@@ -1,0 +1,366 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs.  Tolerance: 1e-4 relative on fp32 activations
+(BASELINE.json north_star); index arrays are consumed bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def da():
+    import dorylus_amd
+    return dorylus_amd
+
+
+def _golden_partitions(name):
+    import partition_oracle as po
+    d = os.path.join(ROOT, "tests", "golden", name)
+    bins = sorted(glob.glob(os.path.join(d, "graph.*.bin")), key=lambda p: int(p.split(".")[-2]))
+    gs = [po.parse_graph_bin(open(b, "rb").read()) for b in bins]
+    parts = np.loadtxt(os.path.join(d, "graph.bsnap.parts"), dtype=np.int64, ndmin=1)
+    return gs, parts
+
+
+@pytest.mark.parametrize("F", [7, 16, 41, 128, 602, 1433])
+@pytest.mark.parametrize("case", ["parts_toy60_p1", "parts_toy60_p2", "parts_toy97_p8_und", "parts_toy40_p3_empty"])
+def test_aggregate_gcn_forward_backward_vs_oracle(da, case, F):
+    """K1 on the reference-built CSC/CSR of the golden partitions, ghosts included."""
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, parts = _golden_partitions(case)
+    rng = np.random.default_rng(F)
+    for r, g in enumerate(gs):
+        N = g["localVtxCnt"]
+        ctx = make_ctx(da, g, [F, F, 3], g["globalVtxCnt"], node_id=r, num_nodes=len(gs))
+        x = rng.standard_normal((N, F)).astype(np.float32)
+        fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
+        gr = rng.standard_normal((N, F)).astype(np.float32)
+        bg = rng.standard_normal((g["dstGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "x", x)
+        ctx.upload(0, "fg", fg)
+        ctx.upload(1, "grad", gr)
+        ctx.upload(0, "bg", bg)
+        for order in (1, 0):
+            ctx.set_option("spmm_order", order)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            ah = ctx.download(0, "ah")
+            aTg = ctx.download(0, "aTg")
+            ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
+            ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
+            assert rel_err(ah, ref_f) < 1e-5, (case, r, F, order)
+            assert rel_err(aTg, ref_b) < 1e-5, (case, r, F, order)
+        ctx.close()
+
+
+@pytest.mark.parametrize("slab", [0, 32, 64, 128, 256])
+def test_aggregate_feature_slabs(da, slab):
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, _ = _golden_partitions("parts_toy60_p2")
+    g = gs[0]
+    F = 602
+    rng = np.random.default_rng(1)
+    ctx = make_ctx(da, g, [F, 8, 3], g["globalVtxCnt"], node_id=0, num_nodes=2)
+    x = rng.standard_normal((g["localVtxCnt"], F)).astype(np.float32)
+    fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
+    ctx.upload(0, "x", x)
+    ctx.upload(0, "fg", fg)
+    ctx.set_option("spmm_slab", slab)
+    ctx.aggregate(0, da.FORWARD)
+    ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
+    assert rel_err(ctx.download(0, "ah"), ref) < 1e-5
+    ctx.close()
+
+
+def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01):
+    """P partitions as P contexts on one GPU; the transport between them is a host
+    copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
+    import torch
+    from dorylus_amd.halo import halo_plan
+    from helpers import make_ctx
+    P = len(gs)
+    V = int(gs[0]["globalVtxCnt"])
+    ctxs, engs, plans = [], [], []
+    for r, g in enumerate(gs):
+        ctx = make_ctx(da, g, dims, V, node_id=r, num_nodes=P)
+        ctx.upload(0, "x", X[g["localToGlobal"]])
+        ctx.upload(0, "fg", X[g["srcGhost"]].reshape(g["srcGhostCnt"], dims[0]))
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l, W in enumerate(Ws):
+            ctx.weight_set(l, "w", W)
+        ctx.adam_config(lr)
+        pl = halo_plan(g, parts, r, P)
+        for d in (0, 1):
+            ctx.halo_plan(d, pl[d][0], pl[d][1])
+        ctxs.append(ctx)
+        plans.append(pl)
+    L = len(dims) - 1
+
+    def exchange(layer, d):
+        # widths travel padded (ld); transport = device-to-device copies by torch
+        src_name, src_layer = ("h", layer - 1) if d == 0 else ("grad", layer)
+        _, _, ld, _ = ctxs[0].info(src_layer, src_name)
+        send = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][0])) * ld, device="cuda") for r in range(P)]
+        recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][1])) * ld, device="cuda") for r in range(P)]
+        for r in range(P):
+            ctxs[r].halo_pack(layer, d, send[r].data_ptr())
+            ctxs[r].sync()
+        for r in range(P):
+            soff = np.concatenate([[0], np.cumsum([len(x) for x in plans[r][d][0]])])
+            for p in range(P):
+                roff = np.concatenate([[0], np.cumsum([len(x) for x in plans[p][d][1]])])
+                n = len(plans[r][d][0][p])
+                assert n == len(plans[p][d][1][r])
+                recv[p][roff[r] * ld:(roff[r] + n) * ld] = send[r][soff[p] * ld:(soff[p] + n) * ld]
+        torch.cuda.synchronize()
+        for r in range(P):
+            ctxs[r].halo_unpack(layer, d, recv[r].data_ptr())
+            ctxs[r].sync()
+
+    stats = []
+    for ep in range(epochs):
+        # stage order of the reference epoch
+        for l in range(L):
+            if l > 0:
+                exchange(l, da.FORWARD)
+            for c in ctxs:
+                c.aggregate(l, da.FORWARD)
+                c.apply_vertex(l, da.FORWARD)
+        stats.append([c.train_stat() for c in ctxs])
+        dWs = {}
+        dWs[L - 1] = sum(c.weight_grad_get(L - 1) for c in ctxs)
+        for l in range(L - 1, 0, -1):
+            exchange(l, da.BACKWARD)
+            for c in ctxs:
+                c.aggregate(l, da.BACKWARD)
+                c.apply_vertex(l - 1, da.BACKWARD)
+            dWs[l - 1] = sum(c.weight_grad_get(l - 1) for c in ctxs)
+        if epochs > 1:
+            for c in ctxs:
+                for l in range(L - 1, -1, -1):
+                    c.weight_update(l)
+    return ctxs, dWs, stats
+
+
+@pytest.mark.parametrize("case,dims", [
+    ("parts_toy60_p1", [13, 8, 5]),
+    ("parts_toy60_p2", [602, 128, 41]),
+    ("parts_toy60_p4_hash", [33, 16, 7]),
+    ("parts_toy97_p8_und", [20, 12, 9, 4]),
+])
+def test_gcn_epoch_vs_oracle(da, case, dims):
+    """Whole forward+backward epoch, every named tensor, P partitions with halo."""
+    from helpers import oracle_gcn_epoch, rel_err
+    gs, parts = _golden_partitions(case)
+    V = int(gs[0]["globalVtxCnt"])
+    rng = np.random.default_rng(7)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)
+          for i in range(len(dims) - 1)]
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws)
+    T, dW = oracle_gcn_epoch(gs, parts, X, labels, Ws, V)
+    L = len(dims) - 1
+    for r, c in enumerate(ctxs):
+        if gs[r]["localVtxCnt"] == 0:
+            continue
+        for l in range(L):
+            assert rel_err(c.download(l, "ah"), T[r][f"ah{l}"]) < RTOL, (r, l, "ah")
+            if l < L - 1:
+                assert rel_err(c.download(l, "z"), T[r][f"z{l}"]) < RTOL
+                assert rel_err(c.download(l, "h"), T[r][f"h{l}"]) < RTOL
+                assert rel_err(c.download(l, "aTg"), T[r][f"aTg{l}"]) < RTOL
+                assert rel_err(c.download(l, "g"), T[r][f"g{l}"]) < RTOL
+            if l > 0:
+                assert rel_err(c.download(l, "grad"), T[r][f"grad{l}"]) < RTOL, (r, l, "grad")
+                assert rel_err(c.download(l, "fg"), T[r][f"fg{l}"]) == 0.0      # halo rows are copies
+                assert rel_err(c.download(l - 1, "bg"), T[r][f"bg{l-1}"]) < RTOL
+        assert rel_err(c.download(L - 1, "g"), T[r]["d"]) < RTOL
+        a, lo, n = stats[0][r]
+        assert abs(a - T[r]["acc"]) < 1e-3 and abs(lo - T[r]["loss"]) < 1e-3 * max(1.0, abs(T[r]["loss"]))
+    for l in range(L):
+        assert rel_err(dWs[l], dW[l]) < RTOL, ("dW", l)
+    for c in ctxs:
+        c.close()
+
+
+def test_gcn_numpy_gnn_fixture(da, golden_dir):
+    """Against the reference's own Python GCN (fixture from miscs/numpy-gnn)."""
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
+    V = int(z["V"])
+    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    dims = [z["X"].shape[1], z["W0"].shape[1], z["W1"].shape[1]]
+    ctx = make_ctx(da, g, dims, V)
+    ctx.upload(0, "x", z["X"])
+    ctx.weight_set(0, "w", z["W0"])
+    ctx.weight_set(1, "w", z["W1"])
+    ctx.labels_upload(z["labels"])
+    ctx.aggregate(0, da.FORWARD)
+    ctx.apply_vertex(0, da.FORWARD)
+    ctx.aggregate(1, da.FORWARD)
+    assert rel_err(ctx.download(0, "ah"), z["ah0"]) < RTOL
+    assert rel_err(ctx.download(0, "z"), z["z0"]) < RTOL
+    assert rel_err(ctx.download(0, "h"), z["h0"]) < RTOL
+    assert rel_err(ctx.download(1, "ah"), z["ah1"]) < RTOL
+    ctx.apply_vertex(1, da.FORWARD)
+    assert rel_err(ctx.download(1, "z"), z["z1"]) < RTOL
+    ctx.close()
+
+
+def test_adam_and_xavier_vs_oracle(da):
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph, rel_err
+    V, dims = 64, [10, 6, 4]
+    s, d = random_graph(3, V, 300)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    ctx = make_ctx(da, g, dims, V)
+    ctx.weights_init_xavier()
+    W = [ctx.weight_get(0), ctx.weight_get(1)]
+    assert np.array_equal(W[0], orc.xavier(10, 6)) and np.array_equal(W[1], orc.xavier(6, 4))
+    rng = np.random.default_rng(0)
+    ctx.upload(0, "x", rng.uniform(-1, 1, (V, 10)).astype(np.float32))
+    ctx.labels_upload(rng.integers(0, 4, V).astype(np.uint32))
+    ctx.adam_config(0.01)
+    eng = da.Engine(ctx, da.GCN, 2)
+    m = [np.zeros_like(w) for w in W]
+    v = [np.zeros_like(w) for w in W]
+    for ep in range(1, 4):
+        ctx.aggregate(0, da.FORWARD); ctx.apply_vertex(0, da.FORWARD)
+        ctx.aggregate(1, da.FORWARD); ctx.apply_vertex(1, da.FORWARD)
+        ctx.aggregate(1, da.BACKWARD); ctx.apply_vertex(0, da.BACKWARD)
+        grads = [ctx.weight_grad_get(0), ctx.weight_grad_get(1)]
+        ctx.weight_update(1)
+        ctx.weight_update(0)
+        for l in (1, 0):
+            orc.adam_update(W[l], grads[l], m[l], v[l], 0.01, ep)
+        for l in (0, 1):
+            assert rel_err(ctx.weight_get(l), W[l]) < 1e-6, (ep, l)
+    ctx.close()
+
+
+def test_engine_epoch_matches_manual_order(da):
+    """dorylus_amd.Engine (reference stage order / chunk state machine) == manual calls."""
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph
+    V, dims = 80, [12, 8, 5]
+    s, d = random_graph(5, V, 500)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-1, 1, (V, 12)).astype(np.float32)
+    lab = rng.integers(0, 5, V).astype(np.uint32)
+    out = []
+    for mode in ("engine", "manual"):
+        ctx = make_ctx(da, g, dims, V)
+        ctx.weights_init_xavier()
+        ctx.upload(0, "x", X)
+        ctx.labels_upload(lab)
+        ctx.adam_config(0.01)
+        if mode == "engine":
+            eng = da.Engine(ctx, da.GCN, 2)
+            for ep in range(3):
+                eng.run_epoch(ep + 1)
+        else:
+            for ep in range(3):
+                ctx.aggregate(0, 0); ctx.apply_vertex(0, 0)
+                ctx.aggregate(1, 0); ctx.apply_vertex(1, 0); ctx.weight_update(1)
+                ctx.aggregate(1, 1); ctx.apply_vertex(0, 1); ctx.weight_update(0)
+        out.append([ctx.weight_get(0), ctx.weight_get(1)])
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("case,dims", [("parts_toy60_p1", [9, 6, 4]), ("parts_toy60_p2", [30, 16, 5])])
+def test_gat_stages_vs_oracle(da, case, dims):
+    """K5 + GAT aggregate forward/backward (parity vs reference unpinned; oracle = restatement)."""
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, parts = _golden_partitions(case)
+    rng = np.random.default_rng(11)
+    for r, g in enumerate(gs):
+        N, E = g["localVtxCnt"], g["localInEdgeCnt"]
+        ctx = make_ctx(da, g, dims, g["globalVtxCnt"], gnn=da.GAT, node_id=r, num_nodes=len(gs))
+        F = dims[1]
+        h = rng.uniform(-1, 1, (N, dims[0])).astype(np.float32)
+        W = (rng.standard_normal((dims[0], F)) / 3).astype(np.float32)
+        a = rng.standard_normal((F, 1)).astype(np.float32)
+        ctx.upload(0, "h", h)
+        ctx.weight_set(0, "w", W)
+        ctx.weight_set(0, "a_i", a)
+        ctx.apply_vertex(0, da.FORWARD)
+        z = ctx.download(0, "z")
+        assert rel_err(z, orc.sgemm(h, W)) < RTOL
+        fgz = rng.uniform(-1, 1, (g["srcGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "fg_z", fgz)
+        ctx.apply_edge(1, da.FORWARD)
+        az_ref, A_ref = orc.edge_forward_gat(g["colPtr"], z, a)
+        assert rel_err(ctx.download(0, "az").ravel(), az_ref) < RTOL
+        assert rel_err(ctx.download(0, "A").ravel(), A_ref) < RTOL
+        ctx.aggregate(1, da.FORWARD)
+        A = ctx.download(0, "A").ravel()
+        assert rel_err(ctx.download(0, "ah"), orc.aggregate_gat_fwd(g["colPtr"], g["rowIdx"], A, z, fgz)) < RTOL
+        # backward
+        grad = rng.uniform(-1, 1, (N, F)).astype(np.float32)
+        bgd = rng.uniform(-1, 1, (g["dstGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "grad", grad)
+        ctx.upload(0, "bg_d", bgd)
+        ctx.apply_edge(1, da.BACKWARD)
+        az = ctx.download(0, "az").ravel()
+        dA_ref, da_ref = orc.edge_backward_gat(g["colPtr"], grad, az, z, a)
+        assert rel_err(ctx.download(0, "dA").ravel(), dA_ref) < RTOL
+        assert rel_err(ctx.weight_grad_get(0, "a_i").ravel(), da_ref) < 5e-4
+        ctx.aggregate(1, da.BACKWARD)
+        dA = ctx.download(0, "dA").ravel()
+        ref = orc.aggregate_gat_bwd(g["rowPtr"], g["colIdx"], g["csrVal"], grad, bgd,
+                                    g["colPtr"], g["rowIdx"], dA, z, fgz)
+        assert rel_err(ctx.download(0, "aTg"), ref) < RTOL
+        ctx.apply_vertex(0, da.BACKWARD)
+        assert rel_err(ctx.weight_grad_get(0), orc.sgemm(h, ctx.download(0, "aTg"), ta=True)) < RTOL
+        ctx.close()
+
+
+def test_fill_uniform_matches_host_twin(da):
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph, splitmix_uniform
+    V = 50
+    s, d = random_graph(2, V, 100)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    ctx = make_ctx(da, g, [37, 8, 3], V)
+    ids = np.arange(V, dtype=np.uint32)[::-1].copy()
+    ctx.fill_uniform(0, "x", 12345, -1.0, 1.0, ids)
+    assert np.array_equal(ctx.download(0, "x"), splitmix_uniform(12345, ids, 37))
+    ctx.close()
+
+
+def test_errors_do_not_abort(da):
+    import partition_oracle as po
+    from helpers import random_graph
+    ctx = da.Context(0)
+    with pytest.raises(da.DoryError):
+        ctx.preallocate()                       # not configured
+    ctx.configure(da.GCN, [4, 3, 2], 10)
+    s, d = random_graph(1, 10, 20)
+    g = po.preprocess(s, d, np.zeros(10, np.int64), 0, 1)
+    bad = dict(g)
+    bad["rowIdx"] = g["rowIdx"].copy()
+    if bad["rowIdx"].size:
+        bad["rowIdx"][0] = 1000
+        with pytest.raises(da.DoryError):
+            ctx.graph_upload(bad)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    with pytest.raises(da.DoryError):
+        ctx.aggregate(7, da.FORWARD)
+    with pytest.raises(da.DoryError):
+        ctx.download(0, "nope")
+    ctx.close()
