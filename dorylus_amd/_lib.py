@@ -21,7 +21,7 @@ SYMBOLS = [
     "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
     "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
-    "dory_timing_get", "dory_timing_reset", "dory_set_option",
+    "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_ctx_describe",
 ]
 
 FORWARD, BACKWARD = 0, 1
@@ -74,6 +74,22 @@ def load():
         "dory_timing_get": [vp, cp, C.POINTER(C.c_double), C.POINTER(u64)],
         "dory_timing_reset": [vp],
         "dory_set_option": [vp, cp, C.c_int64],
+        "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
+        # include/dorylus_host.h
+        "dory_partition_build": [vp, vp, u64, vp, u32, u32, u32, i32, C.POINTER(vp)],
+        "dory_partition_build_from_files": [cp, u32, u32, i32, C.POINTER(vp)],
+        "dory_partition_load": [cp, C.POINTER(vp)],
+        "dory_partition_save": [vp, cp],
+        "dory_partition_free": [vp],
+        "dory_partition_get": [vp, vp],
+        "dory_partition_upload": [vp, vp, vp],
+        "dory_engine_create": [vp, C.POINTER(vp)],
+        "dory_engine_destroy": [vp],
+        "dory_engine_run": [vp, u32, vp],
+        "dory_engine_nn_compute": [vp, vp],
+        "dory_engine_inc_layer": [vp, vp, vp],
+        "dory_engine_is_last_layer": [vp, vp],
+        "dory_engine_report": [vp, cp, C.c_size_t],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -81,6 +97,8 @@ def load():
         fn.restype = i32
     lib.dory_last_error.argtypes = [vp]
     lib.dory_last_error.restype = cp
+    lib.dory_host_last_error.argtypes = []
+    lib.dory_host_last_error.restype = cp
     return lib
 
 

@@ -897,6 +897,18 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
 }
 
 // ---------------------------------------------------------------------------------------
+int dory_ctx_describe(dory_ctx *c, int *gnn_type, uint32_t *num_layers, uint32_t *node_id, uint32_t *num_nodes,
+                      uint32_t *local_vtx_cnt) {
+    CHECK_CTX(c);
+    if (!c->configured || !c->has_graph) return fail(c, DORY_ERR_ARG, "ctx_describe: configure and graph_upload first");
+    if (gnn_type) *gnn_type = c->gnn;
+    if (num_layers) *num_layers = c->L;
+    if (node_id) *node_id = c->nodeId;
+    if (num_nodes) *num_nodes = c->numNodes;
+    if (local_vtx_cnt) *local_vtx_cnt = c->N;
+    return DORY_OK;
+}
+
 int dory_timing_enable(dory_ctx *c, int on) {
     CHECK_CTX(c);
     drain_timing(c);

@@ -6,9 +6,12 @@ ResourceComm::NNCompute) -> SC (scatter*) -> AE (applyEdge*) -> GA ...; in cpu/g
 mode there is exactly one chunk [0, N) per partition (engine/utils.cpp:598-609).
 Every stage is one C-ABI call; nothing here computes.
 """
+import ctypes as C
 from dataclasses import dataclass, replace
 
-from ._lib import BACKWARD, FORWARD, GAT, GCN, Context
+import numpy as np
+
+from ._lib import BACKWARD, FORWARD, GAT, GCN, Context, DoryError
 
 
 @dataclass
@@ -143,3 +146,33 @@ class Engine:
                     self.applyEdgeGAT(c)
                     self.aggregateGAT(c)
         return self.incLayerGCN(c) if self.gnn_type == GCN else self.incLayerGAT(c)
+
+
+class NativeEngine:
+    """The C++ Engine mirror (host/engine.cpp, include/dorylus_host.h): whole epochs run
+    inside the library, no Python between stages."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = C.c_void_p()
+        rc = ctx.lib.dory_engine_create(ctx.h, C.byref(h))
+        if rc != 0:
+            raise DoryError(f"dory_engine_create failed ({rc}): {ctx.lib.dory_last_error(ctx.h).decode()}")
+        self.h = h
+
+    def run(self, epochs):
+        ms = np.zeros(epochs, np.float64)
+        rc = self.ctx.lib.dory_engine_run(self.h, epochs, ms.ctypes.data)
+        if rc != 0:
+            raise DoryError(f"dory_engine_run failed ({rc}): {self.ctx.lib.dory_last_error(self.ctx.h).decode()}")
+        return ms
+
+    def report(self):
+        buf = C.create_string_buffer(2048)
+        self.ctx.lib.dory_engine_report(self.h, buf, 2048)
+        return buf.value.decode()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dory_engine_destroy(self.h)
+            self.h = None

@@ -165,6 +165,9 @@ int dory_adam_config(dory_ctx *ctx, float learning_rate);
 int dory_weight_update(dory_ctx *ctx, uint32_t layer);
 
 /* ---- introspection -------------------------------------------------------------- */
+/* what dory_configure / dory_graph_upload recorded (any pointer may be NULL) */
+int dory_ctx_describe(dory_ctx *ctx, int *gnn_type, uint32_t *num_layers, uint32_t *node_id,
+                      uint32_t *num_nodes, uint32_t *local_vtx_cnt);
 /* average device time (ms) and launch count of a kernel family since the last
  * reset, measured with HIP events on the stream the kernel runs on; names:
  * "spmm", "gemm", "loss", "edge", "halo", "adam". */

@@ -1,0 +1,91 @@
+/*
+ * dorylus_host.h -- C-ABI of the host-side pieces either side of the hot path:
+ * the partition builder / graph.<id>.bin reader-writer (the data format the
+ * kernels consume) and the synchronous-epoch Engine driver.  Same library as
+ * dorylus_hip.h (libdorylus_hip.so).  Reference citations are relative to
+ * src/graph-server/ of uclasystem/dorylus.
+ */
+#ifndef DORYLUS_HOST_H
+#define DORYLUS_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dorylus_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- one partition of the graph on the host: every field of graph.<id>.bin ---- */
+typedef struct dory_partition dory_partition;
+
+/* DataLoader::preprocess (graph/dataloader.cpp:225-330) on in-memory edge records:
+ * local ids ascend with global id, ghost ids are N + rank in ascending global id,
+ * edges inside a column/row keep record order (duplicates kept, self loops dropped),
+ * edge values (indeg(src)+1)^-1/2 (indeg(dst)+1)^-1/2 computed like
+ * setEdgeNormalizations (:153-185), ghost degrees like findGhostDegrees (:192-218).
+ * parts[v] = partition of global vertex v.  Index-identical to the reference. */
+int dory_partition_build(const uint32_t *src, const uint32_t *dst, uint64_t num_records,
+                         const int32_t *parts, uint32_t global_vtx_cnt, uint32_t node_id,
+                         uint32_t num_nodes, int undirected, dory_partition **out);
+/* same, reading <dataset_dir>graph.bsnap.edges and graph.bsnap.parts
+ * (dataloader.cpp:8-10; dataset_dir ends with '/') */
+int dory_partition_build_from_files(const char *dataset_dir, uint32_t node_id, uint32_t num_nodes,
+                                    int undirected, dory_partition **out);
+/* Graph::init (graph/graph.cpp:7-115) / RawGraph::dump (graph.cpp:200-273) */
+int dory_partition_load(const char *graph_bin_path, dory_partition **out);
+int dory_partition_save(const dory_partition *p, const char *graph_bin_path);
+int dory_partition_free(dory_partition *p);
+const char *dory_host_last_error(void);
+
+struct dory_partition_view {
+    uint32_t local_vtx_cnt, global_vtx_cnt, src_ghost_cnt, dst_ghost_cnt, num_nodes;
+    uint64_t local_in_edge_cnt, local_out_edge_cnt, global_edge_cnt;
+    const uint32_t *local_to_global; /* N */
+    const float *norms;              /* N   vtxDataVec */
+    const uint32_t *src_ghosts;      /* Gsrc global ids, ascending (local id = N + k) */
+    const uint32_t *dst_ghosts;      /* Gdst */
+    const uint32_t *fwd_counts;      /* num_nodes: forwardGhostsList sizes */
+    const uint32_t *fwd_lists;       /* concatenated local ids */
+    const uint32_t *bwd_counts;
+    const uint32_t *bwd_lists;
+    const uint64_t *column_ptrs;     /* N+1  forwardAdj  */
+    const uint32_t *row_idxs;
+    const float *csc_values;
+    const uint64_t *row_ptrs;        /* N+1  backwardAdj */
+    const uint32_t *column_idxs;
+    const float *csr_values;
+};
+int dory_partition_get(const dory_partition *p, struct dory_partition_view *view);
+
+/* upload adjacency (dory_graph_upload) and, when parts is given, both halo plans
+ * (dory_halo_plan): recv slots of peer q = ghost slots whose owner is q, ascending. */
+int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t *parts);
+
+/* ---- synchronous-epoch Engine (the reference's stage order, one chunk per
+ * partition: engine/engine.cpp:223-314, ops/pipeline.cpp, resource_comm.cpp) ------ */
+typedef struct dory_engine dory_engine;
+int dory_engine_create(dory_ctx *ctx, dory_engine **out);
+int dory_engine_destroy(dory_engine *e);
+/* run `epochs` epochs back to back; per-epoch wall time (ms, host clock around a
+ * stream sync, as pipeline.cpp:118-127 measures consecutive epoch starts) is
+ * written to epoch_ms[epochs] when non-NULL. */
+int dory_engine_run(dory_engine *e, uint32_t epochs, double *epoch_ms);
+/* single stages with the reference's Chunk semantics (for tests / foreign drivers) */
+struct dory_chunk { /* common/utils.hpp:64-75 */
+    uint32_t localId, globalId, lowBound, upBound, layer;
+    int32_t dir;
+    uint32_t epoch;
+    uint8_t vertex;
+};
+int dory_engine_nn_compute(dory_engine *e, struct dory_chunk *chunk);   /* ResourceComm::NNCompute */
+int dory_engine_inc_layer(dory_engine *e, const struct dory_chunk *in, struct dory_chunk *out); /* incLayerGCN/GAT */
+int dory_engine_is_last_layer(dory_engine *e, const struct dory_chunk *c);
+/* "<EM>: ..." style report of the last run into buf (engine/utils.cpp:219-291) */
+int dory_engine_report(dory_engine *e, char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DORYLUS_HOST_H */

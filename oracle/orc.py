@@ -1,12 +1,12 @@
-"""ctypes front-end for oracle/liboracle.so (TEST INFRASTRUCTURE: the checker)."""
+"""ctypes front-end for oracle/liboracle.so -- TEST INFRASTRUCTURE (the checker and the
+reported CPU baseline); never imported by the product package dorylus_amd/."""
 import ctypes as C
 import os
 import subprocess
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_ORC = os.path.join(ROOT, "oracle")
+_ORC = os.path.dirname(os.path.abspath(__file__))
 
 
 def _build():

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "dorylus_hip.h")).read()
+def _declared(header="dorylus_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dory_[a-z0-9_]+)\s*\(", src)))
 
@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(dorylus_amd.LIB_PATH):
         pytest.skip("library not built (run __graft_entry__.build())")
     lib = ctypes.CDLL(dorylus_amd.LIB_PATH)
-    for s in _declared():
+    for s in _declared() + _declared("dorylus_host.h"):
         assert hasattr(lib, s), s
 
 
