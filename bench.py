@@ -226,6 +226,18 @@ def cpu_baseline(ctx, g, rows):
         tail = Xfull[rows:] if rows < N else np.zeros((1, F), np.float32)   # "ghost" rows = rest of the buffer
         orc.lib.orc_aggregate_gcn(rows, F, ptr, idx, val, norm, Xfull[:rows], tail, out)
         return out
+    # thread count: all hardware threads vs one per physical core -- keep whichever the
+    # memory-bound aggregation runs faster with (the reference just takes OMP defaults)
+    best = None
+    for nt in sorted({ncores, max(1, ncores // 2)}, reverse=True):
+        orc.lib.orc_set_threads(nt)
+        t0 = time.perf_counter()
+        agg(cptr, cidx, cval, H)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    ncores = best[0]
+    orc.lib.orc_set_threads(ncores)
     t = [time.perf_counter()]
     ah0 = agg(cptr, cidx, cval, X); t.append(time.perf_counter())              # GA  L0 fwd
     z0, h0 = orc.vtx_forward_hidden(ah0, W0); t.append(time.perf_counter())     # AV  L0 fwd
@@ -241,7 +253,7 @@ def cpu_baseline(ctx, g, rows):
     return {"value": edges / total, "unit": "edges/s", "cores": ncores, "kind": "port",
             "sample": f"one epoch restricted to the first {rows} destination rows of the same graph "
                       f"({e_in} in-edges, {e_out} out-edges): 3 aggregations + 5 GEMMs + activations/loss, "
-                      f"{total:.2f} s of CPU time, OpenMP over vertices on all {ncores} hardware threads",
+                      f"{total:.2f} s of CPU time, OpenMP over vertices, {ncores} threads",
             "stage_s": {n: round(t[i + 1] - t[i], 3) for i, n in enumerate(names)},
             "gpu_vs_oracle_rel_err_ah0": err}
 

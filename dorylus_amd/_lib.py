@@ -83,6 +83,7 @@ def load():
         "dory_partition_free": [vp],
         "dory_partition_get": [vp, vp],
         "dory_partition_upload": [vp, vp, vp],
+        "dory_partition_recv_plan": [vp, vp, i32, vp, vp],
         "dory_engine_create": [vp, C.POINTER(vp)],
         "dory_engine_destroy": [vp],
         "dory_engine_run": [vp, u32, vp],

@@ -150,7 +150,7 @@ hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uin
                                const float *lab, uint32_t ldl, float *d, uint32_t ldd,
                                float denom, uint32_t val_stt, uint32_t val_end,
                                uint64_t mask_first, uint64_t mask_count, float *stat,
-                               hipStream_t s);
+                               float *stat_partial /* 2 * ceil(val_rows/256) floats */, hipStream_t s);
 // predictGAT: grad = softmax(z) - lab
 hipError_t launch_softmax_sub(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
                               const float *lab, uint32_t ldl, float *out, uint32_t ldo, hipStream_t s);

@@ -90,15 +90,17 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(
 
 // CPUComm::getTrainStat (CPU_comm.cpp:448-462): over validation rows
 // [val_stt, val_end): acc += lab[argmax(pred)], loss -= log(pred[argmax(lab)]).
-// Single workgroup, fixed reduction order -> deterministic.  (thrust functors in
-// the CUDA backend: comp_unit.cu:258-312, cuda_ops.cuh:45-113.)
-__global__ __launch_bounds__(1024) void train_stat_kernel(uint32_t cols, const float *z, uint32_t ldz,
-                                                          const float *lab, uint32_t ldl,
-                                                          uint32_t val_stt, uint32_t val_end,
-                                                          float *stat) {
-    __shared__ float sa[1024], sl[1024];
+// One row per thread, per-block tree sums, then one block adds the block partials
+// in index order -> deterministic.  (thrust functors in the CUDA backend:
+// comp_unit.cu:258-312, cuda_ops.cuh:45-113.)
+__global__ __launch_bounds__(256) void train_stat_kernel(uint32_t cols, const float *z, uint32_t ldz,
+                                                         const float *lab, uint32_t ldl,
+                                                         uint32_t val_stt, uint32_t val_end,
+                                                         float *partial) {
+    __shared__ float sa[256], sl[256];
     float acc = 0.f, loss = 0.f;
-    for (uint32_t r = val_stt + threadIdx.x; r < val_end; r += 1024) {
+    const uint32_t r = val_stt + blockIdx.x * 256 + threadIdx.x;
+    if (r < val_end) {
         const float *zr = z + (size_t)r * ldz;
         const float *lr = lab + (size_t)r * ldl;
         float mx = zr[0];
@@ -110,13 +112,13 @@ __global__ __launch_bounds__(1024) void train_stat_kernel(uint32_t cols, const f
         }
         float den = 1e-20f;
         for (uint32_t c = 0; c < cols; ++c) den += expf(zr[c] - mx);
-        acc += lr[am];
-        loss -= logf(expf(zr[al] - mx) / den);
+        acc = lr[am];
+        loss = -logf(expf(zr[al] - mx) / den);
     }
     sa[threadIdx.x] = acc;
     sl[threadIdx.x] = loss;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             sa[threadIdx.x] += sa[threadIdx.x + o];
             sl[threadIdx.x] += sl[threadIdx.x + o];
@@ -124,18 +126,32 @@ __global__ __launch_bounds__(1024) void train_stat_kernel(uint32_t cols, const f
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        stat[0] = sa[0];
-        stat[1] = sl[0];
+        partial[2 * blockIdx.x] = sa[0];
+        partial[2 * blockIdx.x + 1] = sl[0];
+    }
+}
+__global__ void train_stat_final_kernel(const float *partial, uint32_t nb, float *stat) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.f, l = 0.f;
+        for (uint32_t b = 0; b < nb; ++b) {
+            a += partial[2 * b];
+            l += partial[2 * b + 1];
+        }
+        stat[0] = a;
+        stat[1] = l;
     }
 }
 
 hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
                                const float *lab, uint32_t ldl, float *d, uint32_t ldd, float denom,
                                uint32_t val_stt, uint32_t val_end, uint64_t mask_first,
-                               uint64_t mask_count, float *stat, hipStream_t s) {
+                               uint64_t mask_count, float *stat, float *stat_partial, hipStream_t s) {
     if (rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(train_stat_kernel, dim3(1), dim3(1024), 0, s, cols, z, ldz, lab, ldl, val_stt,
-                       val_end, stat);
+    const uint32_t nb = (val_end - val_stt + 255) / 256;
+    if (nb)
+        hipLaunchKernelGGL(train_stat_kernel, dim3(nb), dim3(256), 0, s, cols, z, ldz, lab, ldl, val_stt,
+                           val_end, stat_partial);
+    hipLaunchKernelGGL(train_stat_final_kernel, dim3(1), dim3(64), 0, s, stat_partial, nb, stat);
     hipLaunchKernelGGL(softmax_xent_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, rows, cols, z, ldz,
                        lab, ldl, d, ldd, denom, mask_first, mask_count, 0);
     return hipGetLastError();

@@ -375,6 +375,24 @@ int dory_partition_get(const dory_partition *p, struct dory_partition_view *v) {
     return DORY_OK;
 }
 
+int dory_partition_recv_plan(const dory_partition *p, const int32_t *parts, int dir, uint32_t *recv_counts,
+                             uint32_t *recv_slots) {
+    if (!p || !parts || !recv_counts || (dir != 0 && dir != 1)) return herr(DORY_ERR_ARG, "recv_plan: bad arguments");
+    const std::vector<uint32_t> &ghost = dir == 0 ? p->srcGhost : p->dstGhost;
+    std::vector<std::vector<uint32_t>> per(p->P);
+    for (uint32_t k = 0; k < ghost.size(); ++k) {
+        const int32_t o = parts[ghost[k]];
+        if (o < 0 || (uint32_t)o >= p->P) return herr(DORY_ERR_ARG, "recv_plan: ghost owner out of range");
+        per[(uint32_t)o].push_back(k);
+    }
+    size_t off = 0;
+    for (uint32_t q = 0; q < p->P; ++q) {
+        recv_counts[q] = (uint32_t)per[q].size();
+        for (uint32_t k : per[q]) recv_slots[off++] = k;
+    }
+    return DORY_OK;
+}
+
 int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t *parts) {
     if (!ctx || !p) return herr(DORY_ERR_ARG, "partition_upload: bad arguments");
     int rc = dory_graph_upload(ctx, p->N, p->Gsrc, p->Gdst, p->nin, p->colPtr.data(), p->rowIdx.data(),
@@ -384,18 +402,12 @@ int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t 
     // receive side of the plan: peer q's k-th row lands in the k-th ghost slot owned by q
     for (int dir = 0; dir < 2; ++dir) {
         const std::vector<uint32_t> &ghost = dir == 0 ? p->srcGhost : p->dstGhost;
-        std::vector<uint32_t> rcnt(p->P, 0), rslots;
-        std::vector<std::vector<uint32_t>> per(p->P);
-        for (uint32_t k = 0; k < ghost.size(); ++k) per[(uint32_t)parts[ghost[k]]].push_back(k);
-        for (uint32_t q = 0; q < p->P; ++q) {
-            rcnt[q] = (uint32_t)per[q].size();
-            rslots.insert(rslots.end(), per[q].begin(), per[q].end());
-        }
+        std::vector<uint32_t> rcnt(p->P, 0), rslots(ghost.size() + 1, 0);
+        if ((rc = dory_partition_recv_plan(p, parts, dir, rcnt.data(), rslots.data()))) return rc;
         const std::vector<uint32_t> &scnt = dir == 0 ? p->fwdCnt : p->bwdCnt;
         const std::vector<uint32_t> &slist = dir == 0 ? p->fwdList : p->bwdList;
         uint32_t dummy = 0;
-        rc = dory_halo_plan(ctx, dir, scnt.data(), slist.empty() ? &dummy : slist.data(), rcnt.data(),
-                            rslots.empty() ? &dummy : rslots.data());
+        rc = dory_halo_plan(ctx, dir, scnt.data(), slist.empty() ? &dummy : slist.data(), rcnt.data(), rslots.data());
         if (rc) return rc;
     }
     return DORY_OK;

@@ -101,6 +101,19 @@ class Partition:
             rowPtr=_arr(v.row_ptrs, N + 1, np.uint64), colIdx=_arr(v.column_idxs, v.local_out_edge_cnt, np.uint32),
             csrVal=_arr(v.csr_values, v.local_out_edge_cnt, np.float32))
 
+    def recv_plan(self, parts, direction):
+        """per-peer lists of ghost slots that peer's rows land in (host/partition.cpp)."""
+        v = self.view()
+        P = int(v["numNodes"])
+        G = int(v["srcGhostCnt"] if direction == 0 else v["dstGhostCnt"])
+        p = np.ascontiguousarray(parts, np.int32)
+        cnt = np.zeros(P, np.uint32)
+        slots = np.zeros(G + 1, np.uint32)
+        self._ck(self.lib, self.lib.dory_partition_recv_plan(self.h, p.ctypes.data, direction,
+                                                              cnt.ctypes.data, slots.ctypes.data))
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        return [slots[off[i]:off[i + 1]].copy() for i in range(P)]
+
     def upload(self, ctx, parts=None):
         """dory_graph_upload + both halo plans (when the .parts vector is given)."""
         p = None if parts is None else np.ascontiguousarray(parts, np.int32)

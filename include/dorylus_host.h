@@ -59,6 +59,13 @@ struct dory_partition_view {
 };
 int dory_partition_get(const dory_partition *p, struct dory_partition_view *view);
 
+/* receive side of the halo plan for direction dir (0 forward / 1 backward): for each
+ * peer q, recv_counts[q] rows arrive (in the sender's list order) and land in ghost
+ * slots recv_slots[off_q .. off_q + recv_counts[q]) -- the ghost slots owned by q in
+ * ascending global id.  recv_counts has num_nodes entries, recv_slots src/dst_ghost_cnt. */
+int dory_partition_recv_plan(const dory_partition *p, const int32_t *parts, int dir,
+                             uint32_t *recv_counts, uint32_t *recv_slots);
+
 /* upload adjacency (dory_graph_upload) and, when parts is given, both halo plans
  * (dory_halo_plan): recv slots of peer q = ghost slots whose owner is q, ascending. */
 int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t *parts);

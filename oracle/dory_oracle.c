@@ -29,6 +29,25 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* thread control for the timed CPU baseline (the reference relies on OMP defaults) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 #define TRAIN_PORTION 0.66 /* common/utils.hpp:60 */
 #define VAL_PORTION 0.1    /* common/utils.hpp:61 */
 

@@ -43,6 +43,8 @@ lib.orc_adam_lr_t.argtypes = [C.c_float, C.c_uint]
 lib.orc_adam_lr_t.restype = C.c_float
 lib.orc_adam_update.argtypes = [C.c_size_t, C.c_float, _f, _f, _f, _f]
 lib.orc_xavier_init.argtypes = [C.c_uint, C.c_uint, _f]
+lib.orc_set_threads.argtypes = [C.c_int]
+lib.orc_get_max_threads.restype = C.c_int
 
 
 def _c(a, dt=np.float32):

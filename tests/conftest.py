@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch first: the library and torch must share ONE HIP runtime (same SONAME)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

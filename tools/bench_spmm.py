@@ -14,11 +14,11 @@ import torch  # noqa: E402  (first: one HIP runtime)
 import dorylus_amd as da  # noqa: E402
 
 
-def synth_csc(N, E, kind, seed=42):
+def synth_csc(N, E, kind, seed=42, window=0):
     g = torch.Generator(device="cuda").manual_seed(seed)
     if kind == "uniform":
         dst = torch.randint(0, N, (E,), device="cuda", generator=g)
-        src = torch.randint(0, N, (E,), device="cuda", generator=g, dtype=torch.int32)
+        src = torch.randint(0, window or N, (E,), device="cuda", generator=g, dtype=torch.int32)
     else:  # rmat-like skew: product of uniform powers concentrates on low ids
         u = torch.rand(E, device="cuda", generator=g)
         dst = (u.pow(3.0) * N).long().clamp_(max=N - 1)
@@ -41,11 +41,12 @@ def main():
     ap.add_argument("--graph", default="uniform")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--slabs", type=int, nargs="+", default=[0, 256, 128, 64, 32])
+    ap.add_argument("--window", type=int, default=0, help="draw sources from [0, window): L2-resident gather probe")
     a = ap.parse_args()
     N = 232965
     E = int(114615892 * a.scale)
     t0 = time.time()
-    ptr, idx, val, maxdeg = synth_csc(N, E, a.graph)
+    ptr, idx, val, maxdeg = synth_csc(N, E, a.graph, window=a.window)
     print(f"graph {a.graph}: N={N} E={E} maxdeg={maxdeg} gen {time.time()-t0:.1f}s", flush=True)
     g = dict(localVtxCnt=N, srcGhostCnt=0, dstGhostCnt=0, colPtr=ptr, rowIdx=idx, cscVal=val,
              rowPtr=ptr, colIdx=idx, csrVal=val, norm=np.full(N, 0.002, np.float32))
