@@ -189,6 +189,19 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """hardware threads this process may really use: affinity mask capped by the cgroup
+    CPU quota (the GPU box shows 256 CPUs but grants 16 via cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(ctx, g, rows):
     """Times oracle/ (the CPU restatement of the reference's cpu backend: aggregateGCN +
     CPUComm::vtxNN*GCN) on this box's host cores over a bounded sample of the same
@@ -200,7 +213,7 @@ def cpu_baseline(ctx, g, rows):
     import orc
     N = int(g["localVtxCnt"])
     V = int(g["globalVtxCnt"])
-    ncores = os.cpu_count() or 1
+    ncores = usable_cpus()
     if rows <= 0:
         rows = min(N, 40000)
     rows = min(rows, N)
