@@ -157,9 +157,16 @@ def main():
     launches_per_epoch = 3
     avg_launch_ms = spmm_ms / max(spmm_n, 1)
     achieved = (algo / launches_per_epoch) / (avg_launch_ms * 1e-3) / 1e9   # GB/s per average launch
+    traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if world == 1 and args.graph == "uniform" and args.scale == 1.0:
+            traffic = pm["spmm_variant_1"]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
-                "kernel": "spmm_rows_kernel", "avg_launch_ms": round(avg_launch_ms, 4),
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "kernel": "spmm_blocked_kernel<16> + spmm_reduce_kernel (K1b; one aggregate = both)", "avg_launch_ms": round(avg_launch_ms, 4),
                 "algorithmic_bytes_per_launch": int(algo / launches_per_epoch),
                 "gather_bytes_per_launch": int((2 * nnz_in * 0 + (nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4) / 3)}
 

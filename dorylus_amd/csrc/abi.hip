@@ -192,9 +192,11 @@ int dory_create(int device, dory_ctx **out) {
     }
     hipMemset(c->d_stat, 0, 2 * sizeof(float));
     c->own_compute = c->own_comm = true;
-    c->opt["spmm_variant"] = 0;
+    c->opt["spmm_variant"] = 1;      // 1: K1b source-blocked L2-resident gather where it applies, 0: K1 only
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;
+    c->opt["spmm_blk_group"] = 16;   // K1b: lanes per row (slab = 4*group floats)
+    c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
     return DORY_OK;
 }
@@ -207,6 +209,9 @@ static void free_graph(dory_ctx *c) {
     c->rowIdx = c->colIdx = nullptr;
     c->cscVal = c->csrVal = c->norm = nullptr;
     c->orderIn = c->orderOut = nullptr;
+    free_blocked(&c->blkIn);
+    free_blocked(&c->blkOut);
+    c->blkIn_built = c->blkOut_built = false;
     c->has_graph = false;
 }
 
@@ -228,6 +233,7 @@ int dory_destroy(dory_ctx *c) {
         if (c->plan[d].d_recv_slots) hipFree(c->plan[d].d_recv_slots);
     }
     if (c->scratch) hipFree(c->scratch);
+    if (c->partial) hipFree(c->partial);
     if (c->send_buf) hipFree(c->send_buf);
     if (c->recv_buf) hipFree(c->recv_buf);
     if (c->d_stat) hipFree(c->d_stat);
@@ -533,6 +539,41 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.xl = xl.d; a.xg = xg ? xg->d : nullptr; a.out = out.d;
     a.accumulate = accumulate;
     a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
+    // K1b (source-blocked, L2-resident gather) needs static values: the adjacency's own
+    // value array (GCN).  GAT's per-layer A / dA live in other arrays -> K1.
+    const bool static_vals = (val == (csc ? c->cscVal : c->csrVal)) && c->gnn == DORY_GCN;
+    if (c->opt["spmm_variant"] == 1 && static_vals && c->N > 0 && a.ld >= 32) {
+        BlockedAdj &B = csc ? c->blkIn : c->blkOut;
+        bool &built = csc ? c->blkIn_built : c->blkOut_built;
+        int group = (int)c->opt["spmm_blk_group"];
+        if (group != 8 && group != 16 && group != 32) group = 16;
+        const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
+        if (built && want_nb && B.nb != (want_nb + 7) / 8 * 8) {  // tuning knob changed: rebuild
+            HIPCK(c, hipStreamSynchronize(c->compute));
+            free_blocked(&B);
+            built = false;
+        }
+        if (!built) {
+            const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
+            HIPCK(c, build_blocked(a.ptr, a.idx, a.val, c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb,
+                                   (uint32_t)group * 16u, &B, c->compute));
+            built = true;
+        }
+        const size_t need = blocked_partial_bytes(a, B);
+        if (B.nb > 0 && need <= ((size_t)48 << 30)) {
+            if (need > c->partial_bytes) {
+                HIPCK(c, hipStreamSynchronize(c->compute));
+                if (c->partial) hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
+            Timed t(c, "spmm", c->compute);
+            HIPCK(c, launch_spmm_blocked(a, B, c->partial, group, c->compute));
+            return DORY_OK;
+        }
+    }
     Timed t(c, "spmm", c->compute);
     HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
     return DORY_OK;

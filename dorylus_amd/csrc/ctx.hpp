@@ -41,6 +41,15 @@ struct HaloPlan {
     uint32_t *d_recv_slots = nullptr;  // concat over peers
 };
 
+// K1b: source-blocked adjacency (per-block CSR over the virtual source space [local;ghost])
+struct BlockedAdj {
+    uint32_t nb = 0;        // number of source blocks (multiple of 8: one per XCD per round)
+    uint32_t SB = 0;        // rows per block
+    uint64_t *bbase = nullptr;  // nb+1: first edge of each block
+    uint32_t *boff = nullptr;   // [nb][N+1]: row offsets inside the block
+    uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order
+    float *bval = nullptr;      // nnz
+};
 struct AdamState {
     float lr = 0.01f;
     unsigned epochs = 1;  // AdamOptimizer ctor calls nextIteration() once
@@ -73,6 +82,11 @@ struct dory_ctx {
     float *cscVal = nullptr, *csrVal = nullptr, *norm = nullptr;
     // longest-row-first schedules for the SpMM (built at upload)
     uint32_t *orderIn = nullptr, *orderOut = nullptr;
+    // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
+    dory::BlockedAdj blkIn, blkOut;
+    bool blkIn_built = false, blkOut_built = false;
+    float *partial = nullptr;
+    size_t partial_bytes = 0;
 
     // tensors / weights
     bool prealloc = false;
@@ -125,6 +139,14 @@ struct SpmmArgs {
     const uint32_t *order;  // optional row schedule (longest first) or nullptr
 };
 hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);
+
+hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
+                         uint64_t nnz, uint32_t want_nb /*0 = auto*/, uint32_t row_bytes, BlockedAdj *out,
+                         hipStream_t s);
+void free_blocked(BlockedAdj *B);
+size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
+hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
+                               hipStream_t s);
 
 // K2  fp32 MFMA GEMM  C = op(A) op(B) with fused epilogues
 enum GemmEpilogue { EPI_NONE = 0, EPI_TANH = 1 /* also writes tanh(C) to C2 */ };

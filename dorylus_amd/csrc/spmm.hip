@@ -22,6 +22,8 @@
 //     keeps the gathered working set N x slab x 4 B small enough for the 256 MB
 //     Infinity Cache.
 //   * optional row schedule (longest row first) for skewed degree distributions.
+#include <vector>
+
 #include "ctx.hpp"
 
 namespace dory {
@@ -170,6 +172,264 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
     if (ch <= 128) return launch_t<64, 2>(a, s);
     if (ch <= 192) return launch_t<64, 3>(a, s);
     return launch_t<64, 4>(a, s);           // wider rows: gridDim.y slabs of 1024 floats
+}
+
+// =======================================================================================
+// K1b: source-blocked, XCD-aware variant -- gathers served from the 4 MB per-XCD L2.
+//
+// Measured on MI355X (profiles/r01_spmm_l2_window_probe.txt): the row gather of K1 runs
+// at ~7.4 TB/s whenever the source operand does not fit L2 (every miss crosses the
+// fabric; rocprof FETCH_SIZE = E*ld*4, no reuse), but at 18-20 TB/s when the sources of
+// all concurrently running workgroups of an XCD lie inside a <= 4 MB window.
+// On a random graph that window has to be imposed:
+//   * the virtual source space [local rows ; ghost rows] is cut into nb = 8k blocks of SB
+//     rows; the edges are regrouped once (build_blocked) into a per-block CSR
+//     (block-major, row-minor, original edge order inside a (block,row) segment);
+//   * features are processed in slabs of W = 64 floats (256 B per row), so one block's
+//     working set is SB * 256 B (3.7 MB at Reddit scale, nb = 16);
+//   * workgroup id -> (xcd = id % 8, slab, round, tile): block b = round*8 + xcd, so the
+//     workgroups the hardware places on XCD x (observed: id % 8; used for speed only,
+//     never for correctness) all gather from block b's window at the same time;
+//   * each (block,row) segment yields a partial row slab, written once to
+//     partial[b][v][slab]; spmm_reduce_kernel adds self term + partials in block order.
+// The price is one partial buffer of nb * N * ld floats written and read once, and the
+// index arrays re-read once per slab -- streamed HBM traffic that replaces the E*ld*4 B
+// of random fabric traffic (profiles/ has the FETCH_SIZE before/after).
+// Summation order: by block, then edge order inside the block (deterministic; differs
+// from the pure edge order of K1 / the CPU loop by fp32 reassociation, ~1e-7 relative).
+// Applies when the values are static (GCN) and nb stays small; callers fall back to K1.
+// =======================================================================================
+typedef float v4f __attribute__((ext_vector_type(4)));  // native vector for nontemporal ld/st
+constexpr int BLK_ROWS = 64;             // destination rows per workgroup
+
+__global__ __launch_bounds__(256) void blk_count_kernel(uint32_t N, const uint64_t *ptr, const uint32_t *idx,
+                                                        uint32_t SB, uint32_t *cnt /*[nb][N]*/) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) cnt[(size_t)(idx[e] / SB) * N + v] += 1;
+}
+
+// one workgroup per block b: boff[b][0..N] = exclusive scan of cnt[b][0..N), total[b]
+__global__ __launch_bounds__(1024) void blk_scan_kernel(uint32_t N, const uint32_t *cnt, uint32_t *boff,
+                                                        uint64_t *total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (N + 1023) / 1024;
+    const uint32_t lo = min(N, t * per), hi = min(N, lo + per);
+    const uint32_t *c = cnt + (size_t)b * N;
+    uint32_t *o = boff + (size_t)b * (N + 1);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += c[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const uint32_t x = part[i];
+            part[i] = run;
+            run += x;
+        }
+        o[N] = run;
+        total[b] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[t];
+    for (uint32_t i = lo; i < hi; ++i) {
+        o[i] = run;
+        run += c[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, const uint64_t *ptr,
+                                                       const uint32_t *idx, const float *val, uint32_t SB,
+                                                       const uint64_t *bbase, const uint32_t *boff,
+                                                       uint32_t *cursor /*[nb][N] scratch*/, uint32_t *bidx,
+                                                       float *bval) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    for (uint32_t b = 0; b < nb; ++b) cursor[(size_t)b * N + v] = boff[(size_t)b * (N + 1) + v];
+    for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) {   // original order inside each (block,row) segment
+        const uint32_t s = idx[e];
+        const uint32_t b = s / SB;
+        const uint64_t pos = bbase[b] + cursor[(size_t)b * N + v]++;
+        bidx[pos] = s;
+        bval[pos] = val[e];
+    }
+}
+
+hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
+                         uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, BlockedAdj *out, hipStream_t s) {
+    BlockedAdj B{};
+    if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
+    // nb = multiple of 8 (one block per XCD per round) with SB*row_bytes <= ~3.75 MB
+    uint32_t nb = 8;
+    if (want_nb) nb = (want_nb + 7) / 8 * 8;
+    else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > (uint64_t)3932160u && nb < 4096) nb += 8;
+    B.nb = nb;
+    B.SB = (NG + nb - 1) / nb;
+    uint32_t *cnt = nullptr;
+    hipError_t e;
+#define BCK(x) if ((e = (x)) != hipSuccess) return e
+    BCK(hipMalloc((void **)&cnt, (size_t)nb * N * sizeof(uint32_t)));
+    BCK(hipMemsetAsync(cnt, 0, (size_t)nb * N * sizeof(uint32_t), s));
+    BCK(hipMalloc((void **)&B.boff, (size_t)nb * (N + 1) * sizeof(uint32_t)));
+    BCK(hipMalloc((void **)&B.bbase, (size_t)(nb + 1) * sizeof(uint64_t)));
+    BCK(hipMalloc((void **)&B.bidx, (nnz ? nnz : 1) * sizeof(uint32_t)));
+    BCK(hipMalloc((void **)&B.bval, (nnz ? nnz : 1) * sizeof(float)));
+    uint64_t *dtotal = nullptr;
+    BCK(hipMalloc((void **)&dtotal, nb * sizeof(uint64_t)));
+    hipLaunchKernelGGL(blk_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ptr, idx, B.SB, cnt);
+    hipLaunchKernelGGL(blk_scan_kernel, dim3(nb), dim3(1024), 0, s, N, cnt, B.boff, dtotal);
+    std::vector<uint64_t> tot(nb), base(nb + 1, 0);
+    BCK(hipMemcpyAsync(tot.data(), dtotal, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    BCK(hipStreamSynchronize(s));
+    for (uint32_t b = 0; b < nb; ++b) base[b + 1] = base[b] + tot[b];
+    if (base[nb] != nnz) return hipErrorUnknown;
+    BCK(hipMemcpyAsync(B.bbase, base.data(), (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(blk_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nb, ptr, idx, val, B.SB,
+                       B.bbase, B.boff, cnt, B.bidx, B.bval);
+    BCK(hipGetLastError());
+    BCK(hipStreamSynchronize(s));
+    hipFree(cnt);
+    hipFree(dtotal);
+#undef BCK
+    *out = B;
+    return hipSuccess;
+}
+
+void free_blocked(BlockedAdj *B) {
+    if (B->boff) hipFree(B->boff);
+    if (B->bbase) hipFree(B->bbase);
+    if (B->bidx) hipFree(B->bidx);
+    if (B->bval) hipFree(B->bval);
+    *B = BlockedAdj{};
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAdj B, float *partial,
+                                                           uint32_t tiles, uint32_t rounds) {
+    constexpr int RPW = 64 / GROUP;
+    constexpr int BLK_ITER = BLK_ROWS / (4 * RPW);
+    const uint32_t id = blockIdx.x;
+    const uint32_t xcd = id & 7u;
+    uint32_t k = id >> 3;
+    const uint32_t tile = k % tiles;
+    k /= tiles;
+    const uint32_t round = k % rounds;
+    const uint32_t slab = k / rounds;
+    const uint32_t b = round * 8u + xcd;
+    if (b >= B.nb) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane % GROUP;
+    const int gi = lane / GROUP;
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t col = slab * GROUP + li;
+    const bool col_ok = col < nchunk;
+    const uint32_t ccol = col_ok ? col : 0;
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
+    const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg);
+    float4 *p4 = reinterpret_cast<float4 *>(partial) + (size_t)b * a.N * nchunk;
+    const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
+    const uint64_t base = B.bbase[b];
+
+#pragma unroll 1
+    for (int it = 0; it < BLK_ITER; ++it) {
+        const uint32_t v = tile * BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
+        const bool row_ok = v < a.N;
+        uint64_t e = row_ok ? base + boff[v] : 0;
+        const uint64_t end = row_ok ? base + boff[v + 1] : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (e < end) {
+            const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
+            uint32_t my_idx = 0;
+            float my_val = 0.f;
+            if (li < n) {
+                my_idx = __builtin_nontemporal_load(B.bidx + e + li);
+                my_val = __builtin_nontemporal_load(B.bval + e + li);
+            }
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                float4 x[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t s = bcast_u32<GROUP>(my_idx, j + u);
+                    w[u] = bcast_f32<GROUP>(my_val, j + u);
+                    const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
+                    x[u] = row[ccol];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fma4(w[u], x[u], acc);
+            }
+            for (; j < n; ++j) {
+                const uint32_t s = bcast_u32<GROUP>(my_idx, j);
+                const float w = bcast_f32<GROUP>(my_val, j);
+                const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
+                acc = fma4(w, row[ccol], acc);
+            }
+            e += n;
+        }
+        if (row_ok && col_ok) {
+            v4f o = {acc.x, acc.y, acc.z, acc.w};
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(p4 + (size_t)v * nchunk + col));
+        }
+    }
+}
+
+// out[v,:] = self[v]*xl[v,:] + sum_b partial[b][v,:]   (block order; float4 streams)
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(SpmmArgs a, uint32_t nb, const float *partial) {
+    const uint32_t nchunk = a.ld >> 2;
+    const size_t n = (size_t)a.N * nchunk;
+    const float4 *p4 = reinterpret_cast<const float4 *>(partial);
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
+    float4 *out4 = reinterpret_cast<float4 *>(a.out);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.self_mode != 0) {
+            const uint32_t v = (uint32_t)(i / nchunk);
+            const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+            const float4 x = xl4[i];
+            acc = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
+        }
+        for (uint32_t b = 0; b < nb; ++b) {
+            const v4f p = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + (size_t)b * n + i));
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        if (a.accumulate) {
+            const float4 p = out4[i];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        out4[i] = acc;
+    }
+}
+
+size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B) {
+    return (size_t)B.nb * a.N * a.ld * sizeof(float);
+}
+
+hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, hipStream_t s) {
+    if (a.N == 0 || a.ld == 0) return hipSuccess;
+    if ((a.ld & 3) || B.nb == 0 || (group != 8 && group != 16 && group != 32)) return hipErrorInvalidValue;
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t slabs = (nchunk + group - 1) / group;
+    const uint32_t tiles = (a.N + BLK_ROWS - 1) / BLK_ROWS;
+    const uint32_t rounds = (B.nb + 7) / 8;
+    const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (group == 8)
+        hipLaunchKernelGGL(spmm_blocked_kernel<8>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
+    else if (group == 16)
+        hipLaunchKernelGGL(spmm_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
+    else
+        hipLaunchKernelGGL(spmm_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)a.N * nchunk;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(spmm_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial);
+    return hipGetLastError();
 }
 
 }  // namespace dory

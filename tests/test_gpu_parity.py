@@ -47,6 +47,7 @@ def test_aggregate_gcn_forward_backward_vs_oracle(da, case, F):
         ctx.upload(0, "fg", fg)
         ctx.upload(1, "grad", gr)
         ctx.upload(0, "bg", bg)
+        ctx.set_option("spmm_variant", 0)
         for order in (1, 0):
             ctx.set_option("spmm_order", order)
             ctx.aggregate(0, da.FORWARD)
@@ -58,6 +59,54 @@ def test_aggregate_gcn_forward_backward_vs_oracle(da, case, F):
             assert rel_err(ah, ref_f) < 1e-5, (case, r, F, order)
             assert rel_err(aTg, ref_b) < 1e-5, (case, r, F, order)
         ctx.close()
+
+
+@pytest.mark.parametrize("F", [16, 41, 128, 602, 1433])
+@pytest.mark.parametrize("case", ["parts_toy60_p1", "parts_toy60_p2", "parts_toy97_p8_und", "parts_toy40_p3_empty"])
+def test_aggregate_blocked_variant_vs_oracle(da, case, F):
+    """K1b (source-blocked, XCD-aware) == oracle, forward (CSC) and backward (CSR), ghosts included."""
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, parts = _golden_partitions(case)
+    rng = np.random.default_rng(F + 1)
+    for r, g in enumerate(gs):
+        N = g["localVtxCnt"]
+        ctx = make_ctx(da, g, [F, F, 3], g["globalVtxCnt"], node_id=r, num_nodes=len(gs))
+        ctx.set_option("spmm_variant", 1)
+        x = rng.standard_normal((N, F)).astype(np.float32)
+        fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
+        gr = rng.standard_normal((N, F)).astype(np.float32)
+        bg = rng.standard_normal((g["dstGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
+        for _ in range(2):   # second pass reuses the blocked structure
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+        ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
+        ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
+        assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F)
+        assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (case, r, F)
+        ctx.close()
+
+
+def test_blocked_variant_many_blocks(da):
+    """enough source rows for several rounds of 8 blocks (nb = 16+), skewed degrees."""
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    rng = np.random.default_rng(9)
+    V, E, F = 40000, 400000, 64
+    s = rng.integers(0, V, E)
+    d = np.where(rng.random(E) < 0.05, 7, rng.integers(0, V, E))      # one hub destination
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    ctx = make_ctx(da, g, [F, 8, 3], V)
+    x = rng.standard_normal((V, F)).astype(np.float32)
+    ctx.upload(0, "x", x)
+    ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
+    for variant in (0, 1):
+        ctx.set_option("spmm_variant", variant)
+        ctx.aggregate(0, da.FORWARD)
+        assert rel_err(ctx.download(0, "ah"), ref) < 1e-5, variant
+    ctx.close()
 
 
 @pytest.mark.parametrize("slab", [0, 32, 64, 128, 256])
@@ -73,6 +122,7 @@ def test_aggregate_feature_slabs(da, slab):
     fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
     ctx.upload(0, "x", x)
     ctx.upload(0, "fg", fg)
+    ctx.set_option("spmm_variant", 0)
     ctx.set_option("spmm_slab", slab)
     ctx.aggregate(0, da.FORWARD)
     ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--graph", default="uniform")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--slabs", type=int, nargs="+", default=[0, 256, 128, 64, 32])
+    ap.add_argument("--variants", type=int, nargs="+", default=[0])
+    ap.add_argument("--groups", type=int, nargs="+", default=[16])
+    ap.add_argument("--nbs", type=int, nargs="+", default=[0])
     ap.add_argument("--window", type=int, default=0, help="draw sources from [0, window): L2-resident gather probe")
     a = ap.parse_args()
     N = 232965
@@ -58,10 +61,15 @@ def main():
         ctx.fill_uniform(0, "x", 1)
         _, _, ld, _ = ctx.info(0, "x")
         comp = E * 8 + 8 * (N + 1) + 4 * N + 4 * F * N + 4 * F * N
-        for order in (1, 0):
-            for slab in a.slabs:
+        for variant in a.variants:
+          for order in ((1, 0) if variant == 0 else (1,)):
+           for grp, nbq in ([(16, 0)] if variant == 0 else [(g_, n_) for g_ in a.groups for n_ in a.nbs]):
+            for slab in (a.slabs if variant == 0 else [0]):
                 if slab and slab >= ld:
                     continue
+                ctx.set_option("spmm_blk_group", grp)
+                ctx.set_option("spmm_blk_nb", nbq)
+                ctx.set_option("spmm_variant", variant)
                 ctx.set_option("spmm_order", order)
                 ctx.set_option("spmm_slab", slab)
                 ctx.aggregate(0, da.FORWARD)
@@ -74,7 +82,7 @@ def main():
                 ms, n = ctx.timing_get("spmm")
                 ctx.timing_enable(False)
                 t = ms / n * 1e-3
-                print(f"F={F} ld={ld} order={order} slab={slab:4d}: {t*1e3:8.3f} ms  "
+                print(f"F={F} ld={ld} variant={variant} grp={grp} nb={nbq} order={order} slab={slab:4d}: {t*1e3:8.3f} ms  "
                       f"{E/t/1e9:7.2f} Gedge/s  gather {E*ld*4/t/1e12:6.2f} TB/s  "
                       f"compulsory {comp/t/1e12:6.3f} TB/s", flush=True)
         ctx.close()
