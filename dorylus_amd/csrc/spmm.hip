@@ -198,6 +198,10 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
 // Summation order: by block, then edge order inside the block (deterministic; differs
 // from the pure edge order of K1 / the CPU loop by fp32 reassociation, ~1e-7 relative).
 // Applies when the values are static (GCN) and nb stays small; callers fall back to K1.
+// Tried and rejected (profiles/r01_k1b_forms_lds_vs_rowgroup.txt): staging the tile's
+// (idx,val) stream in LDS and splitting edges evenly over lane groups -- 23.0 ms vs
+// 20.3 ms at F=602; the kernel is bound by the L1/TA request path (TA_BUSY ~90 %, L2 hit
+// 85 %), not by lane divergence, and the barriers + 36 KB of LDS cost occupancy.
 // =======================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector for nontemporal ld/st
 constexpr int BLK_ROWS = 64;             // destination rows per workgroup

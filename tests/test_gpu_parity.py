@@ -78,13 +78,13 @@ def test_aggregate_blocked_variant_vs_oracle(da, case, F):
         gr = rng.standard_normal((N, F)).astype(np.float32)
         bg = rng.standard_normal((g["dstGhostCnt"], F)).astype(np.float32)
         ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
-        for _ in range(2):   # second pass reuses the blocked structure
-            ctx.aggregate(0, da.FORWARD)
-            ctx.aggregate(1, da.BACKWARD)
         ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
         ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
-        assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F)
-        assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (case, r, F)
+        for form in (0, 1):      # the second pass reuses the blocked structure
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F, form)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (case, r, F, form)
         ctx.close()
 
 
@@ -96,16 +96,18 @@ def test_blocked_variant_many_blocks(da):
     rng = np.random.default_rng(9)
     V, E, F = 40000, 400000, 64
     s = rng.integers(0, V, E)
-    d = np.where(rng.random(E) < 0.05, 7, rng.integers(0, V, E))      # one hub destination
+    s[: E // 8] = rng.integers(0, 50, E // 8)                          # sources concentrated in block 0
+    d = np.where(rng.random(E) < 0.05, 7, rng.integers(0, V, E))      # one hub destination (> 2048 edges per block)
     g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
     ctx = make_ctx(da, g, [F, 8, 3], V)
     x = rng.standard_normal((V, F)).astype(np.float32)
     ctx.upload(0, "x", x)
     ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
-    for variant in (0, 1):
+    for variant, form, nb in ((0, 0, 0), (1, 0, 0), (1, 0, 24), (1, 0, 8)):
         ctx.set_option("spmm_variant", variant)
+        ctx.set_option("spmm_blk_nb", nb)
         ctx.aggregate(0, da.FORWARD)
-        assert rel_err(ctx.download(0, "ah"), ref) < 1e-5, variant
+        assert rel_err(ctx.download(0, "ah"), ref) < 1e-5, (variant, form, nb)
     ctx.close()
 
 

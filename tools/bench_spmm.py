@@ -21,9 +21,9 @@ def synth_csc(N, E, kind, seed=42, window=0):
         src = torch.randint(0, window or N, (E,), device="cuda", generator=g, dtype=torch.int32)
     else:  # rmat-like skew: product of uniform powers concentrates on low ids
         u = torch.rand(E, device="cuda", generator=g)
-        dst = (u.pow(3.0) * N).long().clamp_(max=N - 1)
+        dst = (u.pow(1.5) * N).long().clamp_(max=N - 1)
         u = torch.rand(E, device="cuda", generator=g)
-        src = (u.pow(3.0) * N).to(torch.int32).clamp_(max=N - 1)
+        src = (u.pow(1.5) * N).to(torch.int32).clamp_(max=N - 1)
         perm = torch.randperm(N, device="cuda", generator=g)
         dst = perm[dst]
         src = perm[src.long()].to(torch.int32)
@@ -32,6 +32,13 @@ def synth_csc(N, E, kind, seed=42, window=0):
     ptr[1:] = torch.cumsum(deg, 0)
     val = torch.rand(E, device="cuda", generator=g) * 0.01
     return ptr.cpu().numpy().astype(np.uint64), src.cpu().numpy().astype(np.uint32), val.cpu().numpy(), int(deg.max())
+
+
+_FORM = {}
+
+
+def ctx_form(ctx):
+    return _FORM.get("f", "-")
 
 
 def main():
@@ -44,6 +51,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0])
     ap.add_argument("--groups", type=int, nargs="+", default=[16])
     ap.add_argument("--nbs", type=int, nargs="+", default=[0])
+    ap.add_argument("--forms", type=int, nargs="+", default=[1])
     ap.add_argument("--window", type=int, default=0, help="draw sources from [0, window): L2-resident gather probe")
     a = ap.parse_args()
     N = 232965
@@ -63,10 +71,12 @@ def main():
         comp = E * 8 + 8 * (N + 1) + 4 * N + 4 * F * N + 4 * F * N
         for variant in a.variants:
           for order in ((1, 0) if variant == 0 else (1,)):
-           for grp, nbq in ([(16, 0)] if variant == 0 else [(g_, n_) for g_ in a.groups for n_ in a.nbs]):
+           for grp, nbq in ([(16, 0)] if variant == 0 else [(g_ + 100 * f_, n_) for f_ in a.forms for g_ in a.groups for n_ in a.nbs]):
             for slab in (a.slabs if variant == 0 else [0]):
                 if slab and slab >= ld:
                     continue
+                _FORM["f"] = grp // 100
+                grp = grp % 100
                 ctx.set_option("spmm_blk_group", grp)
                 ctx.set_option("spmm_blk_nb", nbq)
                 ctx.set_option("spmm_variant", variant)
@@ -82,7 +92,7 @@ def main():
                 ms, n = ctx.timing_get("spmm")
                 ctx.timing_enable(False)
                 t = ms / n * 1e-3
-                print(f"F={F} ld={ld} variant={variant} grp={grp} nb={nbq} order={order} slab={slab:4d}: {t*1e3:8.3f} ms  "
+                print(f"F={F} ld={ld} variant={variant} form={ctx_form(ctx)} grp={grp} nb={nbq} order={order} slab={slab:4d}: {t*1e3:8.3f} ms  "
                       f"{E/t/1e9:7.2f} Gedge/s  gather {E*ld*4/t/1e12:6.2f} TB/s  "
                       f"compulsory {comp/t/1e12:6.3f} TB/s", flush=True)
         ctx.close()
