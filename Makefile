@@ -4,10 +4,11 @@ ARCH  ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
 CSRC = dorylus_amd/csrc
 OBJS = $(CSRC)/abi.o $(CSRC)/spmm.o $(CSRC)/gemm.o $(CSRC)/elementwise.o
-HOSTOBJS = $(patsubst %.cpp,%.o,$(wildcard dorylus_amd/host/*.cpp))
+HOSTOBJS = $(patsubst %.cpp,%.o,$(filter-out %_main.cpp,$(wildcard dorylus_amd/host/*.cpp)))
+GRAPHSERVER = dorylus_amd/graphserver
 LIB  = dorylus_amd/libdorylus_hip.so
 
-all: $(LIB) oracle
+all: $(LIB) $(GRAPHSERVER) oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ctx.hpp include/dorylus_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -18,10 +19,14 @@ dorylus_amd/host/%.o: dorylus_amd/host/%.cpp $(wildcard dorylus_amd/host/*.hpp) 
 $(LIB): $(OBJS) $(HOSTOBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fopenmp $(OBJS) $(HOSTOBJS) -L/opt/rocm/lib -lrccl -o $@
 
+# the reference's `graphserver` command line on the hip backend (run/run-onnode:154-179)
+$(GRAPHSERVER): dorylus_amd/host/graphserver_main.cpp $(LIB)
+	g++ -O2 -std=c++17 -Iinclude dorylus_amd/host/graphserver_main.cpp -Ldorylus_amd -ldorylus_hip -Wl,-rpath,'$$ORIGIN' -o $@
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) $(HOSTOBJS) $(LIB); $(MAKE) -C oracle clean
+	rm -f $(OBJS) $(HOSTOBJS) $(LIB) $(GRAPHSERVER); $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

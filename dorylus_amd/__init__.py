@@ -7,4 +7,4 @@ the reference's Engine stages and file formats (host/), and this thin ctypes lay
 from ._lib import (BACKWARD, FORWARD, GAT, GCN, LIB_PATH, SYMBOLS, Context,  # noqa: F401
                    DoryError, load)
 from .engine import Chunk, Engine, NativeEngine  # noqa: F401
-from .partition import Partition  # noqa: F401
+from .partition import Partition, read_features, read_labels, read_layer_config  # noqa: F401

@@ -84,6 +84,9 @@ def load():
         "dory_partition_get": [vp, vp],
         "dory_partition_upload": [vp, vp, vp],
         "dory_partition_recv_plan": [vp, vp, i32, vp, vp],
+        "dory_read_layer_config": [cp, vp, u32, C.POINTER(u32)],
+        "dory_read_features": [cp, vp, u32, u32, cp, vp, vp],
+        "dory_read_labels": [cp, vp, u32, vp],
         "dory_engine_create": [vp, C.POINTER(vp)],
         "dory_engine_destroy": [vp],
         "dory_engine_run": [vp, u32, vp],
@@ -100,6 +103,8 @@ def load():
     lib.dory_last_error.restype = cp
     lib.dory_host_last_error.argtypes = []
     lib.dory_host_last_error.restype = cp
+    lib.dory_formats_last_error.argtypes = []
+    lib.dory_formats_last_error.restype = cp
     return lib
 
 

@@ -122,3 +122,36 @@ class Partition:
             raise DoryError(f"partition_upload failed ({rc}): {self.lib.dory_last_error(ctx.h).decode()} "
                             f"{self.lib.dory_host_last_error().decode()}")
         ctx.N = int(self.view()["localVtxCnt"])
+
+
+def read_layer_config(path, lib=None):
+    """run/<dataset>.config -> list of layer widths (Engine::readLayerConfigFile)."""
+    lib = lib or load()
+    dims = np.zeros(64, np.uint32)
+    n = C.c_uint32()
+    rc = lib.dory_read_layer_config(path.encode(), dims.ctypes.data, 64, C.byref(n))
+    if rc != 0:
+        raise DoryError(f"read_layer_config failed ({rc}): {lib.dory_formats_last_error().decode()}")
+    return [int(x) for x in dims[:n.value]]
+
+
+def read_features(path, part, dim, node_id=0, cache_dir=None):
+    """features.bsnap -> (local N x F, ghost Gsrc x F) for this partition (Engine::readFeaturesFile)."""
+    v = part.view()
+    local = np.zeros((int(v["localVtxCnt"]), dim), np.float32)
+    ghost = np.zeros((int(v["srcGhostCnt"]), dim), np.float32)
+    gp = ghost.ctypes.data if ghost.size else None
+    rc = part.lib.dory_read_features(path.encode(), part.h, dim, node_id,
+                                     cache_dir.encode() if cache_dir else None, local.ctypes.data, gp)
+    if rc != 0:
+        raise DoryError(f"read_features failed ({rc}): {part.lib.dory_formats_last_error().decode()}")
+    return local, ghost
+
+
+def read_labels(path, part, kinds):
+    v = part.view()
+    lab = np.zeros(int(v["localVtxCnt"]), np.uint32)
+    rc = part.lib.dory_read_labels(path.encode(), part.h, kinds, lab.ctypes.data)
+    if rc != 0:
+        raise DoryError(f"read_labels failed ({rc}): {part.lib.dory_formats_last_error().decode()}")
+    return lab

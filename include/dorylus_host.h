@@ -70,6 +70,18 @@ int dory_partition_recv_plan(const dory_partition *p, const int32_t *parts, int 
  * (dory_halo_plan): recv slots of peer q = ghost slots whose owner is q, ascending. */
 int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t *parts);
 
+/* ---- input files of the reference graph server (engine/utils.cpp:460-596) ------------- */
+/* run/<dataset>.config: one layer width per line */
+int dory_read_layer_config(const char *path, uint32_t *dims, uint32_t max_dims, uint32_t *count);
+/* features.bsnap {u32 F} + V x F floats -> rows of this partition's local vertices
+ * (N x F) and source ghosts (Gsrc x F); cache_dir (may be NULL) enables the reference's
+ * feats<F>.<node>.bin cache in the dataset directory */
+int dory_read_features(const char *path, const dory_partition *p, uint32_t expect_dim, uint32_t node_id,
+                       const char *cache_dir, float *local, float *ghost);
+/* labels.bsnap {u32 kinds} + V x u32 -> class id per local vertex */
+int dory_read_labels(const char *path, const dory_partition *p, uint32_t expect_kinds, uint32_t *labels);
+const char *dory_formats_last_error(void);
+
 /* ---- synchronous-epoch Engine (the reference's stage order, one chunk per
  * partition: engine/engine.cpp:223-314, ops/pipeline.cpp, resource_comm.cpp) ------ */
 typedef struct dory_engine dory_engine;

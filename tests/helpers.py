@@ -111,3 +111,35 @@ def make_ctx(da, g, dims, globalV, gnn=0, node_id=0, num_nodes=1, device=0):
     ctx.graph_upload(g)
     ctx.preallocate()
     return ctx
+
+
+def oracle_gat_epoch(g, H0, labels, Ws, As):
+    """One synchronous epoch of the reference's GAT prototype on a single partition
+    (no ghosts), stage order of SURVEY.md 3.3, with the C oracle.  Ws[l]: d_l x d_{l+1},
+    As[l]: d_{l+1} x 1 ("a_i")."""
+    L = len(Ws)
+    T = {}
+    feats = H0
+    for l in range(L):
+        z = orc.sgemm(feats, Ws[l])                                               # AV  fwd
+        az, A = orc.edge_forward_gat(g["colPtr"], z, As[l])                       # AE  fwd
+        ah = orc.aggregate_gat_fwd(g["colPtr"], g["rowIdx"], A, z)                # GA  fwd
+        T[f"in{l}"], T[f"z{l}"], T[f"az{l}"], T[f"A{l}"], T[f"ah{l}"] = feats, z, az, A, ah
+        feats = ah
+    C = Ws[-1].shape[1]
+    lab = np.eye(C, dtype=np.float32)[labels]
+    p = np.empty_like(feats)
+    orc.lib.orc_softmax(feats.shape[0], C, np.ascontiguousarray(feats), p)        # predictGAT
+    grad = (p - lab).astype(np.float32)
+    dWs, das = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        T[f"grad{l}"] = grad
+        dA, da = orc.edge_backward_gat(g["colPtr"], grad, T[f"az{l}"], T[f"z{l}"], As[l])   # AE bwd
+        aTg = orc.aggregate_gat_bwd(g["rowPtr"], g["colIdx"], g["csrVal"], grad, None,
+                                    g["colPtr"], g["rowIdx"], dA, T[f"z{l}"], None)           # GA bwd
+        T[f"dA{l}"], T[f"aTg{l}"] = dA, aTg
+        dWs[l] = orc.sgemm(T[f"in{l}"], aTg, ta=True)                                          # AV bwd
+        das[l] = da
+        if l > 0:
+            grad = orc.sgemm(aTg, Ws[l], tb=True)
+    return T, dWs, das

@@ -397,6 +397,50 @@ def test_gat_stages_vs_oracle(da, case, dims):
         ctx.close()
 
 
+def test_gat_engine_epoch_vs_oracle(da):
+    """Whole GAT epoch through the C++ Engine (stage order of pipeline.cpp for GAT) == oracle."""
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, oracle_gat_epoch, random_graph, rel_err
+    V, dims = 300, [24, 16, 6]
+    s, d = random_graph(4, V, 2500)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    rng = np.random.default_rng(2)
+    H0 = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
+    As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(2)]
+    ctx = make_ctx(da, g, dims, V, gnn=da.GAT)
+    ctx.upload(0, "h", H0)
+    ctx.labels_upload(labels)
+    for l in range(2):
+        ctx.weight_set(l, "w", Ws[l])
+        ctx.weight_set(l, "a_i", As[l])
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(1)
+    T, dWs, das = oracle_gat_epoch(g, H0, labels, Ws, As)
+    for l in range(2):
+        assert rel_err(ctx.download(l, "z"), T[f"z{l}"]) < RTOL, l
+        assert rel_err(ctx.download(l, "az").ravel(), T[f"az{l}"]) < RTOL, l
+        assert rel_err(ctx.download(l, "ah"), T[f"ah{l}"]) < RTOL, l
+        assert rel_err(ctx.download(l, "grad"), T[f"grad{l}"]) < RTOL, l
+        assert rel_err(ctx.download(l, "dA").ravel(), T[f"dA{l}"]) < RTOL, l
+        assert rel_err(ctx.download(l, "aTg"), T[f"aTg{l}"]) < RTOL, l
+        assert rel_err(ctx.weight_grad_get(l), dWs[l]) < RTOL, l
+        assert rel_err(ctx.weight_grad_get(l, "a_i").ravel(), das[l]) < 5e-4, l
+    # "w" took one Adam step, "a_i" is left as the (faked) weight server leaves it
+    m = [np.zeros_like(w) for w in Ws]
+    v = [np.zeros_like(w) for w in Ws]
+    for l in (1, 0):
+        W = Ws[l].copy()
+        orc.adam_update(W, dWs[l], m[l], v[l], 0.01, 1)
+        assert rel_err(ctx.weight_get(l), W) < 1e-5
+        assert np.array_equal(ctx.weight_get(l, "a_i"), As[l])
+    eng.close()
+    ctx.close()
+
+
 def test_fill_uniform_matches_host_twin(da):
     import partition_oracle as po
     from helpers import make_ctx, random_graph, splitmix_uniform
