@@ -168,7 +168,7 @@ def main():
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                "kernel": "spmm_blocked_kernel<16> + spmm_reduce_kernel (K1b; one aggregate = both)", "avg_launch_ms": round(avg_launch_ms, 4),
+                "kernel": "spmm_blocked_kernel<32> + spmm_reduce_kernel (K1b; one aggregate = both)", "avg_launch_ms": round(avg_launch_ms, 4),
                 "algorithmic_bytes_per_launch": int(algo / launches_per_epoch),
                 "gather_bytes_per_launch": int((2 * nnz_in * 0 + (nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4) / 3)}
 

@@ -195,7 +195,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_variant"] = 1;      // 1: K1b source-blocked L2-resident gather where it applies, 0: K1 only
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;
-    c->opt["spmm_blk_group"] = 16;   // K1b: lanes per row (slab = 4*group floats)
+    c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
     return DORY_OK;
@@ -546,9 +546,10 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         BlockedAdj &B = csc ? c->blkIn : c->blkOut;
         bool &built = csc ? c->blkIn_built : c->blkOut_built;
         int group = (int)c->opt["spmm_blk_group"];
-        if (group != 8 && group != 16 && group != 32) group = 16;
+        if (group != 8 && group != 16 && group != 32) group = 32;
+        if (a.ld < 128 && group == 32) group = 16;   // narrow tensors: one 256-B slab
         const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
-        if (built && want_nb && B.nb != (want_nb + 7) / 8 * 8) {  // tuning knob changed: rebuild
+        if (built && ((want_nb && B.nb != (want_nb + 7) / 8 * 8) || B.row_bytes != (uint32_t)group * 16u)) {  // knob changed: rebuild
             HIPCK(c, hipStreamSynchronize(c->compute));
             free_blocked(&B);
             built = false;
@@ -557,6 +558,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
             HIPCK(c, build_blocked(a.ptr, a.idx, a.val, c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb,
                                    (uint32_t)group * 16u, &B, c->compute));
+            B.row_bytes = (uint32_t)group * 16u;
             built = true;
         }
         const size_t need = blocked_partial_bytes(a, B);

@@ -45,6 +45,7 @@ struct HaloPlan {
 struct BlockedAdj {
     uint32_t nb = 0;        // number of source blocks (multiple of 8: one per XCD per round)
     uint32_t SB = 0;        // rows per block
+    uint32_t row_bytes = 0; // slab bytes per row the block size was chosen for
     uint64_t *bbase = nullptr;  // nb+1: first edge of each block
     uint32_t *boff = nullptr;   // [nb][N+1]: row offsets inside the block
     uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order

@@ -201,7 +201,9 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
 // Tried and rejected (profiles/r01_k1b_forms_lds_vs_rowgroup.txt): staging the tile's
 // (idx,val) stream in LDS and splitting edges evenly over lane groups -- 23.0 ms vs
 // 20.3 ms at F=602; the kernel is bound by the L1/TA request path (TA_BUSY ~90 %, L2 hit
-// 85 %), not by lane divergence, and the barriers + 36 KB of LDS cost occupancy.
+// 85 %), not by lane divergence, and the barriers + 36 KB of LDS cost occupancy.  A
+// streaming form (consecutive rows per lane group as one edge stream, prefetched refills,
+// 8 rows in flight) was within 2 % of this one (profiles/r01_k1b_forms_stream_vs_rowgroup.txt).
 // =======================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector for nontemporal ld/st
 constexpr int BLK_ROWS = 64;             // destination rows per workgroup
@@ -265,10 +267,14 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
                          uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, BlockedAdj *out, hipStream_t s) {
     BlockedAdj B{};
     if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
-    // nb = multiple of 8 (one block per XCD per round) with SB*row_bytes <= ~3.75 MB
+    // nb = multiple of 8 (one block per XCD per round).  Window SB*row_bytes: measured
+    // optimum (profiles/r01_k1b_param_sweep.txt) is ~3.7 MB at 256-B rows and ~5 MB at
+    // 512-B rows -- a little over the 4 MB L2 is fine (Infinity Cache backs it), shorter
+    // (block,row) segments and more partial traffic are not.
+    const uint64_t window = row_bytes >= 512 ? (uint64_t)5242880u : (uint64_t)3932160u;
     uint32_t nb = 8;
     if (want_nb) nb = (want_nb + 7) / 8 * 8;
-    else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > (uint64_t)3932160u && nb < 4096) nb += 8;
+    else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > window && nb < 4096) nb += 8;
     B.nb = nb;
     B.SB = (NG + nb - 1) / nb;
     uint32_t *cnt = nullptr;

@@ -80,11 +80,12 @@ def test_aggregate_blocked_variant_vs_oracle(da, case, F):
         ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
         ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
         ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
-        for form in (0, 1):      # the second pass reuses the blocked structure
+        for grp in (32, 16, 16):   # same group twice: the second pass reuses the blocked structure
+            ctx.set_option("spmm_blk_group", grp)
             ctx.aggregate(0, da.FORWARD)
             ctx.aggregate(1, da.BACKWARD)
-            assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F, form)
-            assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (case, r, F, form)
+            assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F, grp)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (case, r, F, grp)
         ctx.close()
 
 
@@ -103,11 +104,12 @@ def test_blocked_variant_many_blocks(da):
     x = rng.standard_normal((V, F)).astype(np.float32)
     ctx.upload(0, "x", x)
     ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
-    for variant, form, nb in ((0, 0, 0), (1, 0, 0), (1, 0, 24), (1, 0, 8)):
+    for variant, grp, nb in ((0, 32, 0), (1, 32, 0), (1, 16, 24), (1, 8, 8), (1, 16, 0), (1, 32, 24)):
         ctx.set_option("spmm_variant", variant)
+        ctx.set_option("spmm_blk_group", grp)
         ctx.set_option("spmm_blk_nb", nb)
         ctx.aggregate(0, da.FORWARD)
-        assert rel_err(ctx.download(0, "ah"), ref) < 1e-5, (variant, form, nb)
+        assert rel_err(ctx.download(0, "ah"), ref) < 1e-5, (variant, grp, nb)
     ctx.close()
 
 
