@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw"])
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
+    ap.add_argument("--gnn", default="gcn", choices=["gcn", "gat"],
+                    help="gat = the reference's GAT prototype (BASELINE config 3's weighted-SpMM part); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows sampled for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -95,13 +97,14 @@ def main():
     nnz_in, nnz_out = int(g["localInEdgeCnt"]), int(g["localOutEdgeCnt"])
 
     ctx = da.Context(local_rank)
-    ctx.configure(da.GCN, DIMS, V, rank, world)
+    gat = args.gnn == "gat"
+    ctx.configure(da.GAT if gat else da.GCN, DIMS, V, rank, world)
     part.upload(ctx, parts if world > 1 else None)
     ctx.preallocate()
     # synthetic features: fp32 U(-1,1) keyed by global vertex id (same row whichever rank
     # holds it); layer-0 ghost rows are "loaded from file" once, like fg@0 in the reference
-    ctx.fill_uniform(0, "x", 1, -1.0, 1.0, g["localToGlobal"])
-    if Gs:
+    ctx.fill_uniform(0, "h" if gat else "x", 1, -1.0, 1.0, g["localToGlobal"])
+    if Gs and not gat:
         ctx.fill_uniform(0, "fg", 1, -1.0, 1.0, g["srcGhost"])
     labels = np.random.default_rng(2).integers(0, DIMS[-1], V).astype(np.uint32)
     ctx.labels_upload(labels[g["localToGlobal"]])
@@ -141,6 +144,8 @@ def main():
         E_in, E_out = nnz_in, nnz_out
     ms_per_step = elapsed * 1e3 / args.steps
     edges_per_epoch = 2 * E_in + E_out                       # fwd L0, fwd L1 (CSC) + bwd L1 (CSR)
+    if gat:                                                  # 2 fwd (CSC) + 2 bwd x (CSR + CSC) aggregations
+        edges_per_epoch = 4 * E_in + 2 * E_out
     value = edges_per_epoch / (ms_per_step * 1e-3)
 
     # ---- roofline of the dominant kernel (K1 SpMM): HIP events on its stream, separate epochs ----
@@ -174,16 +179,20 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on this box's cores ----------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat:
         cpu = cpu_baseline(ctx, g, args.cpu_rows)
 
+    if gat:   # the roofline / traffic bookkeeping above is for the GCN epoch's three launches
+        roofline = None
     if rank == 0:
         out = {
-            "metric": "full-graph GCN epoch: aggregated edges/sec (epoch time in ms_per_step), Reddit-scale synthetic, 2-layer 602-128-41",
+            "metric": ("full-graph GAT (reference prototype) epoch: aggregated edges/sec, Reddit-scale synthetic" if gat else
+                       "full-graph GCN epoch: aggregated edges/sec (epoch time in ms_per_step), Reddit-scale synthetic, 2-layer 602-128-41"),
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph",
+            "config": {"workload": ("Reddit GAT 2-layer (reference single-head prototype) full-graph" if gat else
+                                    "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph"),
                        "graph": args.graph, "vertices": V, "edges": E_in, "partitioning": f"contiguous x{world}",
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
