@@ -25,18 +25,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;
 constexpr int BK = 32;
 
-// Stage a (BK x BT) tile into LDS k-major.  kmajor source: elem(k,i) = p[k*ld+i];
-// otherwise elem(k,i) = p[i*ld+k] (transposing copy).
-template <int BT, bool KMAJOR, int LLD>
-__device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ p, uint32_t ld,
-                                           uint32_t ext, uint32_t Kend, uint32_t i0, uint32_t k0) {
+// A (BK x BT) operand tile travels global -> registers -> LDS (k-major).  The two halves
+// are separate so that the loads of tile t+1 are in flight while tile t is multiplied.
+// kmajor source: elem(k,i) = p[k*ld+i]; otherwise elem(k,i) = p[i*ld+k] (transposing copy).
+template <int BT, bool KMAJOR>
+struct TileRegs {
+    static constexpr int N4 = BT * BK / 4 / 256;   // float4 per thread
+    float4 v[N4];
+};
+
+template <int BT, bool KMAJOR>
+__device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR> &r, const float *__restrict__ p, uint32_t ld,
+                                          uint32_t ext, uint32_t Kend, uint32_t i0, uint32_t k0) {
     const int t = threadIdx.x;
     if constexpr (KMAJOR) {
         constexpr int VPR = BT / 4;          // float4 per k-row
         constexpr int KPI = 256 / VPR;       // k rows per iteration
         const int i4 = (t % VPR) * 4;
-        for (int kk = t / VPR; kk < BK; kk += KPI) {
-            const uint32_t k = k0 + kk;
+#pragma unroll
+        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+            const uint32_t k = k0 + t / VPR + it * KPI;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < Kend) {
                 const float *src = p + (size_t)k * ld + i0 + i4;
@@ -48,14 +56,15 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
                     if (i0 + i4 + 2 < ext) v.z = src[2];
                 }
             }
-            *reinterpret_cast<float4 *>(lds + kk * LLD + i4) = v;
+            r.v[it] = v;
         }
     } else {
         constexpr int LPR = BK / 4;          // lanes per row (8)
         constexpr int RPI = 256 / LPR;       // rows per iteration (32)
         const int kq = (t % LPR) * 4;
-        for (int r = t / LPR; r < BT; r += RPI) {
-            const uint32_t i = i0 + r;
+#pragma unroll
+        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+            const uint32_t i = i0 + t / LPR + it * RPI;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < ext) {
                 const float *src = p + (size_t)i * ld + k0 + kq;
@@ -67,10 +76,32 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
                     if (k0 + kq + 2 < Kend) v.z = src[2];
                 }
             }
-            lds[(kq + 0) * LLD + r] = v.x;
-            lds[(kq + 1) * LLD + r] = v.y;
-            lds[(kq + 2) * LLD + r] = v.z;
-            lds[(kq + 3) * LLD + r] = v.w;
+            r.v[it] = v;
+        }
+    }
+}
+
+template <int BT, bool KMAJOR, int LLD>
+__device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR> &r) {
+    const int t = threadIdx.x;
+    if constexpr (KMAJOR) {
+        constexpr int VPR = BT / 4;
+        constexpr int KPI = 256 / VPR;
+        const int i4 = (t % VPR) * 4;
+#pragma unroll
+        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it)
+            *reinterpret_cast<float4 *>(lds + (t / VPR + it * KPI) * LLD + i4) = r.v[it];
+    } else {
+        constexpr int LPR = BK / 4;
+        constexpr int RPI = 256 / LPR;
+        const int kq = (t % LPR) * 4;
+#pragma unroll
+        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+            const int rr = t / LPR + it * RPI;
+            lds[(kq + 0) * LLD + rr] = r.v[it].x;
+            lds[(kq + 1) * LLD + rr] = r.v[it].y;
+            lds[(kq + 2) * LLD + rr] = r.v[it].z;
+            lds[(kq + 3) * LLD + rr] = r.v[it].w;
         }
     }
 }
@@ -80,9 +111,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, fl
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 1;
     constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 1;
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA_S + BK * LDB_S + 8];
-    float *As = smem;
-    float *Bs = smem + ((BK * LDA_S + 3) & ~3);
+    constexpr int A_SZ = (BK * LDA_S + 3) & ~3;
+    constexpr int B_SZ = (BK * LDB_S + 3) & ~3;
+    // two LDS buffers per operand: tile t+1 is written while nobody reads it, one barrier per tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -102,11 +134,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, fl
 
     const int fr = lane & 31;   // row/col inside the 32-wide fragment
     const int fk = lane >> 5;   // k offset inside the 2-deep MFMA
+    TileRegs<BM, A_KMAJOR> ra;
+    TileRegs<BN, B_KMAJOR> rb;
+    int cur = 0;
+    if (kbeg < kend) {
+        tile_load<BM, A_KMAJOR>(ra, g.A, g.lda, g.M, kend, i0, kbeg);
+        tile_load<BN, B_KMAJOR>(rb, g.B, g.ldb, g.N, kend, j0, kbeg);
+        tile_store<BM, A_KMAJOR, LDA_S>(smem, ra);
+        tile_store<BN, B_KMAJOR, LDB_S>(smem + A_SZ, rb);
+    }
+    __syncthreads();
     for (uint32_t k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        stage_tile<BM, A_KMAJOR, LDA_S>(As, g.A, g.lda, g.M, kend, i0, k0);
-        stage_tile<BN, B_KMAJOR, LDB_S>(Bs, g.B, g.ldb, g.N, kend, j0, k0);
-        __syncthreads();
+        const bool more = k0 + BK < kend;
+        if (more) {  // next tile: global -> registers, in flight during the MFMAs below
+            tile_load<BM, A_KMAJOR>(ra, g.A, g.lda, g.M, kend, i0, k0 + BK);
+            tile_load<BN, B_KMAJOR>(rb, g.B, g.ldb, g.N, kend, j0, k0 + BK);
+        }
+        const float *As = smem + cur * (A_SZ + B_SZ);
+        const float *Bs = As + A_SZ;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
@@ -120,6 +165,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, fl
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+        if (more) {
+            float *An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+            tile_store<BM, A_KMAJOR, LDA_S>(An, ra);
+            tile_store<BN, B_KMAJOR, LDB_S>(An + A_SZ, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -143,7 +195,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, fl
         }
 }
 
-// second stage of split-K: C = sum_z partial[z] in z order (deterministic)
+// second stage of split-K: C = sum_z partial[z] in z order (deterministic); eight
+// partials are requested at a time so the loads overlap, the adds stay sequential
 __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M, uint32_t N,
                                      uint32_t ldc, uint32_t S) {
     const size_t n = (size_t)M * ldc;
@@ -151,7 +204,15 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
          i += (size_t)gridDim.x * blockDim.x) {
         if ((i % ldc) >= N) continue;
         float s = 0.f;
-        for (uint32_t z = 0; z < S; ++z) s += partial[(size_t)z * n + i];
+        uint32_t z = 0;
+        for (; z + 8 <= S; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(z + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < S; ++z) s += partial[(size_t)z * n + i];
         C[i] = s;
     }
 }
@@ -159,7 +220,7 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
 static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
     const uint32_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     if (tiles >= 512 || K <= 4096) return 1;
-    uint32_t s = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+    uint32_t s = (512 + tiles - 1) / tiles;             // aim at ~512 workgroups = 256 CUs x 2 resident blocks
     const uint32_t maxs = (K + 4 * BK - 1) / (4 * BK);  // at least 4 k-tiles per split
     if (s > maxs) s = maxs;
     if (s > 512) s = 512;
