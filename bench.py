@@ -49,6 +49,34 @@ def synth_edges(kind, V, E, seed=42):
     return np.concatenate([s, d]), np.concatenate([d, s])
 
 
+def splitmix_uniform(seed, rows_global, cols, lo=-1.0, hi=1.0):
+    """host twin of the device counter RNG (csrc/elementwise.hip fill_uniform_kernel)"""
+    rows_global = np.asarray(rows_global, dtype=np.uint64)
+    idx = rows_global[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) ^ idx) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (np.float32(lo) + (np.float32(hi) - np.float32(lo)) * u).astype(np.float32)
+
+
+def halo_selfcheck(ctx, g, da):
+    """N > 1 only, before any timing: one forward and one backward halo exchange of rows
+    that are a known function of the global vertex id; every received ghost row must be
+    the owner's row bit for bit (plan + pack + RCCL all-to-all-v + unpack end to end)."""
+    ctx.fill_uniform(0, "h", 7, -1.0, 1.0, g["localToGlobal"])
+    ctx.halo_exchange(1, da.FORWARD)
+    ctx.sync()
+    ok = np.array_equal(ctx.download(1, "fg"), splitmix_uniform(7, g["srcGhost"], DIMS[1]))
+    ctx.fill_uniform(1, "grad", 9, -1.0, 1.0, g["localToGlobal"])
+    ctx.halo_exchange(1, da.BACKWARD)
+    ctx.sync()
+    ok = ok and np.array_equal(ctx.download(0, "bg"), splitmix_uniform(9, g["dstGhost"], DIMS[1]))
+    return bool(ok)
+
+
 def spmm_algorithmic_bytes(N, G, E, F):
     """compulsory bytes of one SpMM launch."""
     return E * 8 + 8 * (N + 1) + 4 * N + 4 * F * (N + G) + 4 * F * N
@@ -116,6 +144,13 @@ def main():
             idt.copy_(torch.from_numpy(ctx.comm_unique_id()))
         dist.broadcast(idt, 0)
         ctx.comm_init(idt.cpu().numpy(), rank, world)
+    halo_ok = None
+    if world > 1 and not gat:
+        flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        halo_ok = bool(flag.item())
+        if not halo_ok:
+            raise SystemExit("halo exchange self-check FAILED: received ghost rows differ from the owners' rows")
     eng = da.NativeEngine(ctx)
     t_setup = time.time() - t_setup
 
@@ -128,6 +163,8 @@ def main():
     # ---- warmup, then exactly K timed steps ------------------------------------------
     if args.warmup:
         eng.run(args.warmup)
+    ctx.timing_reset()
+    ctx.timing_enable(True)        # HIP events on the kernels' own stream, over the timed region
     barrier()
     t0 = time.perf_counter()
     epoch_ms = eng.run(args.steps)
@@ -148,11 +185,7 @@ def main():
         edges_per_epoch = 4 * E_in + 2 * E_out
     value = edges_per_epoch / (ms_per_step * 1e-3)
 
-    # ---- roofline of the dominant kernel (K1 SpMM): HIP events on its stream, separate epochs ----
-    ctx.timing_reset()
-    ctx.timing_enable(True)
-    eng.run(3)
-    ctx.sync()
+    # ---- roofline of the dominant kernel (K1 SpMM): HIP events recorded during the timed steps ----
     fam = {}
     for f in ("spmm", "gemm", "loss", "halo", "allreduce", "adam"):
         ms, n = ctx.timing_get(f)
@@ -197,7 +230,8 @@ def main():
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernel_ms_per_epoch": {k: round(v[0] / 3, 4) for k, v in fam.items() if v[1]},
+            "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
+            "halo_selfcheck": halo_ok,
             "setup_s": round(t_setup, 1),
         }
         print(json.dumps(out), flush=True)

@@ -134,7 +134,7 @@ def test_aggregate_feature_slabs(da, slab):
     ctx.close()
 
 
-def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01):
+def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None):
     """P partitions as P contexts on one GPU; the transport between them is a host
     copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
     import torch
@@ -152,8 +152,12 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01):
             ctx.weight_set(l, "w", W)
         ctx.adam_config(lr)
         pl = halo_plan(g, parts, r, P)
-        for d in (0, 1):
-            ctx.halo_plan(d, pl[d][0], pl[d][1])
+        if native_plan is not None:
+            # the C++ path bench.py / graphserver use: dory_partition_upload computes both plans
+            native_plan[r].upload(ctx, parts)
+        else:
+            for d in (0, 1):
+                ctx.halo_plan(d, pl[d][0], pl[d][1])
         ctxs.append(ctx)
         plans.append(pl)
     L = len(dims) - 1
@@ -258,6 +262,33 @@ def test_gcn_epoch_vs_oracle(da, case, dims):
             for k, gv in enumerate(gs[r]["dstGhost"]):
                 o, lv = owner_row[int(gv)]
                 assert np.array_equal(bg[k], grs[o][lv])
+    for c in ctxs:
+        c.close()
+
+
+def test_gcn_epoch_native_partition_and_plan(da):
+    """Same epoch check, but partitions + halo plans come from the C++ host layer
+    (Partition.build -> dory_partition_upload), the path bench.py takes at N > 1."""
+    from helpers import oracle_gcn_epoch, random_graph, rel_err
+    V, P, dims = 500, 4, [40, 24, 6]
+    s, d = random_graph(21, V, 6000)
+    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+    nparts = [da.Partition.build(s, d, parts, r, P) for r in range(P)]
+    gs = [p.view() for p in nparts]
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, native_plan=nparts)
+    T, dW = oracle_gcn_epoch(gs, parts, X, labels, Ws, V)
+    for r, c in enumerate(ctxs):
+        assert rel_err(c.download(1, "ah"), T[r]["ah1"]) < RTOL
+        assert rel_err(c.download(0, "aTg"), T[r]["aTg0"]) < RTOL
+        assert np.array_equal(c.download(1, "fg"), np.concatenate(
+            [ctxs[parts[gv]].download(0, "h")[np.searchsorted(gs[parts[gv]]["localToGlobal"], gv)][None]
+             for gv in gs[r]["srcGhost"]] + [np.zeros((0, dims[1]), np.float32)]))
+    for l in range(2):
+        assert rel_err(dWs[l], dW[l]) < RTOL
     for c in ctxs:
         c.close()
 
