@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
     ap.add_argument("--gnn", default="gcn", choices=["gcn", "gat"],
                     help="gat = the reference's GAT prototype (BASELINE config 3's weighted-SpMM part); not the headline metric")
+    ap.add_argument("--emulate", default="", help="R/P: run rank R's partition of a P-way split alone on one GPU, "
+                    "halo exchange skipped (per-rank compute time of an N-GPU run; diagnostic, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows sampled for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -117,8 +119,11 @@ def main():
     E_target = int(REDDIT_E * args.scale)
     t_setup = time.time()
     src, dst = synth_edges(args.graph, V, E_target)
-    parts = (np.arange(V, dtype=np.int64) * world // V).astype(np.int32)   # contiguous blocks
-    part = da.Partition.build(src, dst, parts, rank, world)
+    pw, pr = world, rank
+    if args.emulate:
+        pr, pw = (int(t) for t in args.emulate.split("/"))
+    parts = (np.arange(V, dtype=np.int64) * pw // V).astype(np.int32)   # contiguous blocks
+    part = da.Partition.build(src, dst, parts, pr, pw)
     del src, dst
     g = part.view()
     N, Gs, Gd = int(g["localVtxCnt"]), int(g["srcGhostCnt"]), int(g["dstGhostCnt"])
@@ -200,7 +205,7 @@ def main():
     traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if world == 1 and args.graph == "uniform" and args.scale == 1.0:
+        if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate:
             traffic = pm["spmm_variant_1"]["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -212,7 +217,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on this box's cores ----------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate:
         cpu = cpu_baseline(ctx, g, args.cpu_rows)
 
     if gat:   # the roofline / traffic bookkeeping above is for the GCN epoch's three launches
@@ -226,7 +231,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("Reddit GAT 2-layer (reference single-head prototype) full-graph" if gat else
                                     "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph"),
-                       "graph": args.graph, "vertices": V, "edges": E_in, "partitioning": f"contiguous x{world}",
+                       "graph": args.graph, "vertices": V, "edges": E_in,
+                       "partitioning": f"contiguous x{world}" + (f" (emulating rank {args.emulate}, no exchange)" if args.emulate else ""),
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -165,6 +165,9 @@ int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const 
 }
 }  // namespace
 
+static int ensure_blocked(dory_ctx *c, bool csc, int group);
+static int blk_group_for(dory_ctx *c, uint32_t ld);
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------
@@ -373,6 +376,12 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "bg_d", c->Gdst, d[l + 1]);
         }
         mk(0, "cw", N, 1);  // column weights for the a_i gradient (K5)
+        for (uint32_t l = 0; l < L; ++l) {
+            mk(l, "arow", N, 1);   // per-destination value of "A"  (all edges of a column are equal)
+            mk(l, "drow", N, 1);   // per-destination value of "dA"
+        }
+        c->gat_arow_valid.assign(L, 0);
+        c->gat_drow_valid.assign(L, 0);
     }
     if (rc) return rc;
     for (uint32_t l = 0; l < L; ++l) {
@@ -389,6 +398,20 @@ int dory_preallocate(dory_ctx *c) {
     }
     c->adam.epochs = 1;
     HIPCK(c, hipStreamSynchronize(c->compute));
+    if (c->opt["spmm_variant"] == 1 && N > 0) {   // K1b: regroup the edges now, not inside the first epoch
+        uint32_t minld = 0xFFFFFFFFu;
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t w = c->gnn == DORY_GCN ? (l == 0 ? d[0] : d[l]) : d[l + 1];
+            minld = std::min(minld, pad_ld(w));
+        }
+        uint32_t maxld = 0;
+        for (uint32_t l = 0; l <= L; ++l) maxld = std::max(maxld, pad_ld(d[l]));
+        const int group = blk_group_for(c, maxld);   // block size for the widest rows (most of the traffic)
+        if (minld >= 32) {
+            if ((rc = ensure_blocked(c, true, group))) return rc;
+            if ((rc = ensure_blocked(c, false, group))) return rc;
+        }
+    }
     c->prealloc = true;
     return DORY_OK;
 }
@@ -440,6 +463,8 @@ int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const floa
     CHECK_CTX(c);
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_upload: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
+    if (!strcmp(name, "dA") && layer < c->gat_drow_valid.size()) c->gat_drow_valid[layer] = 0;
     return upload_dense(c, *t, host);
 }
 
@@ -525,8 +550,40 @@ int dory_weights_init_xavier(dory_ctx *c) {
 }
 
 // ---------------------------------------------------------------------------------------
+// K1b bookkeeping: (re)build the source-blocked copy of one adjacency for `group` lanes/row
+static int ensure_blocked(dory_ctx *c, bool csc, int group) {
+    BlockedAdj &B = csc ? c->blkIn : c->blkOut;
+    bool &built = csc ? c->blkIn_built : c->blkOut_built;
+    const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
+    // the block structure serves every slab width; only an explicit block count forces a rebuild
+    if (built && want_nb && B.nb != (want_nb + 7) / 8 * 8) {
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        free_blocked(&B);
+        built = false;
+    }
+    if (!built) {
+        const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
+        HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
+                               c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute));
+        B.row_bytes = (uint32_t)group * 16u;
+        built = true;
+    }
+    return DORY_OK;
+}
+
+static int blk_group_for(dory_ctx *c, uint32_t ld) {
+    int group = (int)c->opt["spmm_blk_group"];
+    if (group != 8 && group != 16 && group != 32) group = 32;
+    if (ld < 128 && group == 32) group = 16;   // narrow tensors: one 256-B slab
+    return group;
+}
+
+// One aggregation.  Edge weights come from `val` (any per-edge array, K1), or -- when
+// `val` is the adjacency's own static array -- from the source-blocked copy (K1b), or are
+// 1 with a per-destination factor `row_scale` (K1b, unit mode; the reference GAT's edge
+// scores depend on the destination only, CPU_comm.cpp:299-319).
 static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &xl, Tensor *xg, Tensor &out,
-                uint32_t F, int accumulate) {
+                uint32_t F, int accumulate, const float *row_scale = nullptr) {
     if (xl.ld != out.ld || (xg && xg->rows && xg->ld != xl.ld) || xl.cols != F)
         return fail(c, DORY_ERR_ARG, "spmm: tensor shapes disagree (F=%u ld %u/%u)", F, xl.ld, out.ld);
     SpmmArgs a{};
@@ -539,28 +596,12 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.xl = xl.d; a.xg = xg ? xg->d : nullptr; a.out = out.d;
     a.accumulate = accumulate;
     a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
-    // K1b (source-blocked, L2-resident gather) needs static values: the adjacency's own
-    // value array (GCN).  GAT's per-layer A / dA live in other arrays -> K1.
-    const bool static_vals = (val == (csc ? c->cscVal : c->csrVal)) && c->gnn == DORY_GCN;
-    if (c->opt["spmm_variant"] == 1 && static_vals && c->N > 0 && a.ld >= 32) {
+    const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal
+    if (c->opt["spmm_variant"] == 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+        const int group = blk_group_for(c, a.ld);
+        int rc = ensure_blocked(c, csc, group);
+        if (rc) return rc;
         BlockedAdj &B = csc ? c->blkIn : c->blkOut;
-        bool &built = csc ? c->blkIn_built : c->blkOut_built;
-        int group = (int)c->opt["spmm_blk_group"];
-        if (group != 8 && group != 16 && group != 32) group = 32;
-        if (a.ld < 128 && group == 32) group = 16;   // narrow tensors: one 256-B slab
-        const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
-        if (built && ((want_nb && B.nb != (want_nb + 7) / 8 * 8) || B.row_bytes != (uint32_t)group * 16u)) {  // knob changed: rebuild
-            HIPCK(c, hipStreamSynchronize(c->compute));
-            free_blocked(&B);
-            built = false;
-        }
-        if (!built) {
-            const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
-            HIPCK(c, build_blocked(a.ptr, a.idx, a.val, c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb,
-                                   (uint32_t)group * 16u, &B, c->compute));
-            B.row_bytes = (uint32_t)group * 16u;
-            built = true;
-        }
         const size_t need = blocked_partial_bytes(a, B);
         if (B.nb > 0 && need <= ((size_t)48 << 30)) {
             if (need > c->partial_bytes) {
@@ -572,10 +613,11 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 c->partial_bytes = need;
             }
             Timed t(c, "spmm", c->compute);
-            HIPCK(c, launch_spmm_blocked(a, B, c->partial, group, c->compute));
+            HIPCK(c, launch_spmm_blocked(a, B, c->partial, group, row_scale, c->compute));
             return DORY_OK;
         }
     }
+    if (!val) return fail(c, DORY_ERR_ARG, "spmm: no edge values");
     Timed t(c, "spmm", c->compute);
     HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
     return DORY_OK;
@@ -608,9 +650,14 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
     const uint32_t fl = layer - 1;
     NEED(z, fl, "z");
     NEED(fgz, fl, "fg_z");
+    // dory_apply_edge leaves, next to the per-edge tensors "A" / "dA", the one value all
+    // edges of a destination share; while that is current the SpMM gathers unweighted
+    // (K1b) and scales per row.  A caller that overwrote "A"/"dA" gets the general K1 path.
     if (dir == DORY_FORWARD) {
         NEED(ah, fl, "ah");
-        return spmm(c, true, c->cscVal, 2, *z, fgz, *ah, c->dims[layer], 0);
+        Tensor *arow = find(c, fl, "arow");
+        const bool fast = arow && fl < c->gat_arow_valid.size() && c->gat_arow_valid[fl];
+        return spmm(c, true, c->cscVal, 2, *z, fgz, *ah, c->dims[layer], 0, fast ? arow->d : nullptr);
     }
     NEED(grad, fl, "grad");
     NEED(bgd, fl, "bg_d");
@@ -619,7 +666,9 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
     // fresh two-term sum (the CUDA path's semantics, gat_ops.cpp:155-163): A^T.dP then += dA.Z
     int rc = spmm(c, false, c->csrVal, 0, *grad, bgd, *aTg, c->dims[layer], 0);
     if (rc) return rc;
-    return spmm(c, true, dA->d, 0, *z, fgz, *aTg, c->dims[layer], 1);
+    Tensor *drow = find(c, fl, "drow");
+    const bool fast = drow && fl < c->gat_drow_valid.size() && c->gat_drow_valid[fl];
+    return spmm(c, true, dA->d, 0, *z, fgz, *aTg, c->dims[layer], 1, fast ? drow->d : nullptr);
 }
 
 int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
@@ -703,14 +752,18 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     NEED(z, fl, "z");
     NEED(az, fl, "az");
     if (dir == DORY_FORWARD) {  // edgNNForwardGAT (CPU_comm.cpp:190-203)
+        NEED(arow, fl, "arow");
         Timed t(c, "edge", c->compute);
-        HIPCK(c, launch_edge_forward_gat(c->N, F, c->colPtr, z->d, z->ld, a.d, az->d, c->cscVal, c->compute));
+        HIPCK(c, launch_edge_forward_gat(c->N, F, c->colPtr, z->d, z->ld, a.d, az->d, c->cscVal, arow->d, c->compute));
+        for (auto &f : c->gat_arow_valid) f = 0;   // "A" now holds this layer's scores only
+        c->gat_arow_valid[fl] = 1;
         return DORY_OK;
     }
     // edgNNBackwardGAT (CPU_comm.cpp:205-242)
     NEED(grad, fl, "grad");
     NEED(dA, fl, "dA");
     NEED(cw, 0, "cw");
+    NEED(drow, fl, "drow");
     Tensor &da = c->wgrads[fl]["a_i"];
     int rc = ensure_scratch(c, (size_t)(1024 * (size_t)F + F + c->N + 64) * sizeof(float));
     if (rc) return rc;
@@ -719,7 +772,8 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     float *partial = y + ((c->N + 63) & ~63u);
     const size_t pbytes = c->scratch_bytes - (size_t)(partial - c->scratch) * sizeof(float);
     Timed t(c, "edge", c->compute);
-    HIPCK(c, launch_edge_backward_gat(c->N, F, c->colPtr, grad->d, grad->ld, az->d, a.d, dA->d, cw->d, c->compute));
+    HIPCK(c, launch_edge_backward_gat(c->N, F, c->colPtr, grad->d, grad->ld, az->d, a.d, dA->d, cw->d, drow->d, c->compute));
+    c->gat_drow_valid[fl] = 1;
     // r = grad^T cw ; da = z^T (z r)   [= (z^T z) r^T, CPU_comm.cpp:232-236, without the F x F matrix]
     HIPCK(c, launch_colsum_w(c->N, F, grad->d, grad->ld, cw->d, partial, pbytes, r, c->compute));
     HIPCK(c, launch_rowdot(c->N, F, z->d, z->ld, r, y, c->compute));

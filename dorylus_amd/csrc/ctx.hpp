@@ -86,6 +86,8 @@ struct dory_ctx {
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
     bool blkIn_built = false, blkOut_built = false;
+    // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
+    std::vector<char> gat_arow_valid, gat_drow_valid;
     float *partial = nullptr;
     size_t partial_bytes = 0;
 
@@ -147,7 +149,7 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
 void free_blocked(BlockedAdj *B);
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
-                               hipStream_t s);
+                               const float *row_scale /*nullable: unit edge weights, per-row factor*/, hipStream_t s);
 
 // K2  fp32 MFMA GEMM  C = op(A) op(B) with fused epilogues
 enum GemmEpilogue { EPI_NONE = 0, EPI_TANH = 1 /* also writes tanh(C) to C2 */ };
@@ -189,10 +191,12 @@ hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t 
 
 // K5 GAT edge kernels
 hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,
-                                   uint32_t ldz, const float *a, float *az, float *A, hipStream_t s);
+                                   uint32_t ldz, const float *a, float *az, float *A,
+                                   float *arow /*N: the column's A value*/, hipStream_t s);
 hipError_t launch_edge_backward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *grad,
                                     uint32_t ldg, const float *az, const float *a, float *dA,
-                                    float *cw /*N: deg(v)*dLRelu_v*/, hipStream_t s);
+                                    float *cw /*N: deg(v)*dLRelu_v*/, float *drow /*N: the column's dA value*/,
+                                    hipStream_t s);
 hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *r, float *y,
                          hipStream_t s);
 hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *w,

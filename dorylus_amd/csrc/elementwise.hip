@@ -256,7 +256,7 @@ hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t 
 __global__ __launch_bounds__(256) void edge_forward_gat_kernel(uint32_t N, uint32_t F,
                                                                const uint64_t *colptr, const float *z,
                                                                uint32_t ldz, const float *a, float *az,
-                                                               float *A) {
+                                                               float *A, float *arow) {
     const int lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
@@ -269,12 +269,14 @@ __global__ __launch_bounds__(256) void edge_forward_gat_kernel(uint32_t N, uint3
         az[e] = s;
         A[e] = act;
     }
+    if (lane == 0) arow[v] = act;   // every edge of column v carries the same weight
 }
 
 hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,
-                                   uint32_t ldz, const float *a, float *az, float *A, hipStream_t s) {
+                                   uint32_t ldz, const float *a, float *az, float *A, float *arow,
+                                   hipStream_t s) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(edge_forward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, z, ldz, a, az, A);
+    hipLaunchKernelGGL(edge_forward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, z, ldz, a, az, A, arow);
     return hipGetLastError();
 }
 
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void edge_backward_gat_kernel(uint32_t N, uint
                                                                 const uint64_t *colptr,
                                                                 const float *grad, uint32_t ldg,
                                                                 const float *az, const float *a,
-                                                                float *dA, float *cw) {
+                                                                float *dA, float *cw, float *drow) {
     const int lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
@@ -299,15 +301,18 @@ __global__ __launch_bounds__(256) void edge_backward_gat_kernel(uint32_t N, uint
     for (uint32_t j = lane; j < F; j += 64) s = fmaf(gr[j] * sv, a[j], s);
     s = wave_sum(s);
     for (uint64_t e = e0 + lane; e < e1; e += 64) dA[e] = s;
-    if (lane == 0) cw[v] = (float)(e1 - e0) * sv;
+    if (lane == 0) {
+        cw[v] = (float)(e1 - e0) * sv;
+        drow[v] = s;
+    }
 }
 
 hipError_t launch_edge_backward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *grad,
                                     uint32_t ldg, const float *az, const float *a, float *dA, float *cw,
-                                    hipStream_t s) {
+                                    float *drow, hipStream_t s) {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(edge_backward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, grad,
-                       ldg, az, a, dA, cw);
+                       ldg, az, a, dA, cw, drow);
     return hipGetLastError();
 }
 

@@ -315,7 +315,7 @@ void free_blocked(BlockedAdj *B) {
     *B = BlockedAdj{};
 }
 
-template <int GROUP>
+template <int GROUP, bool UNIT>
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAdj B, float *partial,
                                                            uint32_t tiles, uint32_t rounds) {
     constexpr int RPW = 64 / GROUP;
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
         while (e < end) {
             const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
             uint32_t my_idx = 0;
-            float my_val = 0.f;
+            float my_val = 1.f;   // UNIT: unweighted sum (per-row factor applied by the reduce kernel)
             if (li < n) {
                 my_idx = __builtin_nontemporal_load(B.bidx + e + li);
-                my_val = __builtin_nontemporal_load(B.bval + e + li);
+                if constexpr (!UNIT) my_val = __builtin_nontemporal_load(B.bval + e + li);
             }
             int j = 0;
             for (; j + 4 <= n; j += 4) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = bcast_u32<GROUP>(my_idx, j + u);
-                    w[u] = bcast_f32<GROUP>(my_val, j + u);
+                    w[u] = UNIT ? 1.f : bcast_f32<GROUP>(my_val, j + u);
                     const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
                     x[u] = row[ccol];
                 }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
             }
             for (; j < n; ++j) {
                 const uint32_t s = bcast_u32<GROUP>(my_idx, j);
-                const float w = bcast_f32<GROUP>(my_val, j);
+                const float w = UNIT ? 1.f : bcast_f32<GROUP>(my_val, j);
                 const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
                 acc = fma4(w, row[ccol], acc);
             }
@@ -389,23 +389,39 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
 }
 
 // out[v,:] = self[v]*xl[v,:] + sum_b partial[b][v,:]   (block order; float4 streams)
-__global__ __launch_bounds__(256) void spmm_reduce_kernel(SpmmArgs a, uint32_t nb, const float *partial) {
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(SpmmArgs a, uint32_t nb, const float *partial,
+                                                          const float *row_scale) {
     const uint32_t nchunk = a.ld >> 2;
     const size_t n = (size_t)a.N * nchunk;
     const float4 *p4 = reinterpret_cast<const float4 *>(partial);
     const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
     float4 *out4 = reinterpret_cast<float4 *>(a.out);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)(i / nchunk);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.self_mode != 0) {
-            const uint32_t v = (uint32_t)(i / nchunk);
-            const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
-            const float4 x = xl4[i];
-            acc = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
-        }
-        for (uint32_t b = 0; b < nb; ++b) {
-            const v4f p = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + (size_t)b * n + i));
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        if (row_scale) {   // out = self + row_scale[v] * (unweighted neighbour sum)
+            for (uint32_t b = 0; b < nb; ++b) {
+                const v4f p = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + (size_t)b * n + i));
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            const float rs = row_scale[v];
+            acc = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
+            if (a.self_mode != 0) {
+                const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+                const float4 x = xl4[i];
+                acc.x = fmaf(x.x, sc, acc.x); acc.y = fmaf(x.y, sc, acc.y);
+                acc.z = fmaf(x.z, sc, acc.z); acc.w = fmaf(x.w, sc, acc.w);
+            }
+        } else {
+            if (a.self_mode != 0) {
+                const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+                const float4 x = xl4[i];
+                acc = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
+            }
+            for (uint32_t b = 0; b < nb; ++b) {
+                const v4f p = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p4 + (size_t)b * n + i));
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
         }
         if (a.accumulate) {
             const float4 p = out4[i];
@@ -419,7 +435,8 @@ size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B) {
     return (size_t)B.nb * a.N * a.ld * sizeof(float);
 }
 
-hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, hipStream_t s) {
+hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group,
+                               const float *row_scale, hipStream_t s) {
     if (a.N == 0 || a.ld == 0) return hipSuccess;
     if ((a.ld & 3) || B.nb == 0 || (group != 8 && group != 16 && group != 32)) return hipErrorInvalidValue;
     const uint32_t nchunk = a.ld >> 2;
@@ -428,17 +445,22 @@ hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *pa
     const uint32_t rounds = (B.nb + 7) / 8;
     const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (group == 8)
-        hipLaunchKernelGGL(spmm_blocked_kernel<8>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
-    else if (group == 16)
-        hipLaunchKernelGGL(spmm_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
-    else
-        hipLaunchKernelGGL(spmm_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, partial, tiles, rounds);
+    const dim3 gr((uint32_t)grid), bl(256);
+    const bool unit = row_scale != nullptr;   // per-row factor: unweighted gather, scaled in the reduce
+#define LAUNCH_BLK(G)                                                                                           \
+    do {                                                                                                        \
+        if (unit) hipLaunchKernelGGL((spmm_blocked_kernel<G, true>), gr, bl, 0, s, a, B, partial, tiles, rounds);  \
+        else hipLaunchKernelGGL((spmm_blocked_kernel<G, false>), gr, bl, 0, s, a, B, partial, tiles, rounds);      \
+    } while (0)
+    if (group == 8) LAUNCH_BLK(8);
+    else if (group == 16) LAUNCH_BLK(16);
+    else LAUNCH_BLK(32);
+#undef LAUNCH_BLK
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t n = (size_t)a.N * nchunk;
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(spmm_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial);
+    hipLaunchKernelGGL(spmm_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, row_scale);
     return hipGetLastError();
 }
 
