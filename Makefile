@@ -6,9 +6,10 @@ CSRC = dorylus_amd/csrc
 OBJS = $(CSRC)/abi.o $(CSRC)/spmm.o $(CSRC)/gemm.o $(CSRC)/elementwise.o
 HOSTOBJS = $(patsubst %.cpp,%.o,$(filter-out %_main.cpp,$(wildcard dorylus_amd/host/*.cpp)))
 GRAPHSERVER = dorylus_amd/graphserver
+INPUTS = dorylus_amd/dory-inputs
 LIB  = dorylus_amd/libdorylus_hip.so
 
-all: $(LIB) $(GRAPHSERVER) oracle
+all: $(LIB) $(GRAPHSERVER) $(INPUTS) oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ctx.hpp include/dorylus_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -23,10 +24,14 @@ $(LIB): $(OBJS) $(HOSTOBJS)
 $(GRAPHSERVER): dorylus_amd/host/graphserver_main.cpp $(LIB)
 	g++ -O2 -std=c++17 -Iinclude dorylus_amd/host/graphserver_main.cpp -Ldorylus_amd -ldorylus_hip -Wl,-rpath,'$$ORIGIN' -o $@
 
+# inputs/ tool equivalents (graphtobinary, featurestobinary, labelstobinary, partitioner)
+$(INPUTS): dorylus_amd/host/inputs_main.cpp
+	g++ -O2 -std=c++17 dorylus_amd/host/inputs_main.cpp -o $@
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) $(HOSTOBJS) $(LIB) $(GRAPHSERVER); $(MAKE) -C oracle clean
+	rm -f $(OBJS) $(HOSTOBJS) $(LIB) $(GRAPHSERVER) $(INPUTS); $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,74 @@
+"""Host logic (CPU): the inputs/ tool equivalents (dorylus_amd/dory-inputs) write the byte
+formats the graph server reads from the reference's text formats."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import partition_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "dorylus_amd", "dory-inputs")
+pytestmark = pytest.mark.skipif(not os.path.exists(EXE), reason="dory-inputs not built")
+
+
+def run(cwd, *args):
+    r = subprocess.run([EXE, *args], cwd=cwd, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+@pytest.mark.parametrize("undirected", [0, 1])
+def test_graphtobinary(tmp_path, undirected):
+    txt = "# comment\n% another\n0 1\n1 2\n2 2\n5 0\n3 1\n"          # "2 2" is a self loop
+    (tmp_path / "g.txt").write_text(txt)
+    run(tmp_path, "graphtobinary", "g.txt", "--snapfile=g.txt", f"--undirected={undirected}", "--header=1")
+    V, s, d = po.read_bsnap_edges(str(tmp_path / "g.txt.bsnap"))
+    es, ed = [0, 1, 5, 3], [1, 2, 0, 1]
+    if undirected:
+        es, ed = [0, 1, 1, 2, 5, 0, 3, 1], [1, 0, 2, 1, 0, 5, 1, 3]
+    assert V == 6 and list(s) == es and list(d) == ed
+    raw = open(tmp_path / "g.txt.bsnap", "rb").read()
+    assert struct.unpack("<iIQ", raw[:16]) == (4, 6, len(es))
+
+
+def test_features_and_labels_to_binary(tmp_path):
+    (tmp_path / "f.txt").write_text("0.5, 1.25,2\n\n3 4 5\n# skipped\n1e-1,0,7\n")
+    run(tmp_path, "featurestobinary", "--featuresfile=f.txt", "--featuredimension=3")
+    raw = open(tmp_path / "f.txt.bsnap", "rb").read()
+    assert struct.unpack("<I", raw[:4]) == (3,)
+    assert np.allclose(np.frombuffer(raw[4:], np.float32).reshape(-1, 3), [[0.5, 1.25, 2], [3, 4, 5], [0.1, 0, 7]])
+    (tmp_path / "l.txt").write_text("3\n0\n\n 2 \nx\n1\n")
+    run(tmp_path, "labelstobinary", "--labelsfile=l.txt", "--labelkinds=4")
+    raw = open(tmp_path / "l.txt.bsnap", "rb").read()
+    assert struct.unpack("<I", raw[:4]) == (4,) and list(np.frombuffer(raw[4:], np.uint32)) == [3, 0, 2, 1]
+
+
+@pytest.mark.parametrize("method", ["block", "hash", "bfs"])
+def test_partitioner_and_pipeline_into_builder(tmp_path, method):
+    """prepare-style pipeline: text -> bsnap -> .parts -> partition build (the graph server's input)"""
+    rng = np.random.default_rng(1)
+    V, E, P = 120, 700, 4
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    s[0], d[0] = V - 1, 0
+    (tmp_path / "graph").write_text("\n".join(f"{a} {b}" for a, b in zip(s, d)) + "\n")
+    run(tmp_path, "graphtobinary", "--snapfile=graph", "--undirected=0", "--header=1")
+    os.rename(tmp_path / "graph.bsnap", tmp_path / "graph.bsnap.tmp")
+    os.rename(tmp_path / "graph.bsnap.tmp", tmp_path / "graph.bsnap")
+    out = run(tmp_path, "partitioner", "graph.bsnap", str(V), str(P), f"--method={method}")
+    parts = np.loadtxt(tmp_path / f"parts_{P}" / "graph.bsnap.parts", dtype=np.int64)
+    assert parts.size == V and parts.min() == 0 and parts.max() == P - 1
+    counts = np.bincount(parts, minlength=P)
+    assert counts.max() - counts.min() <= max(2, V // 10)                       # balanced
+    keep = s != d
+    cut = int((parts[s[keep]] != parts[d[keep]]).sum())
+    assert f"Communication cost: {cut}" in open(tmp_path / f"parts_{P}" / "graph.bsnap.comm").read()
+    import dorylus_amd as da
+    if os.path.exists(da.LIB_PATH):
+        os.symlink(tmp_path / "graph.bsnap", tmp_path / f"parts_{P}" / "graph.bsnap.edges")   # inputs/prepare:41
+        for nid in range(P):
+            part = da.Partition.build_from_files(str(tmp_path / f"parts_{P}") + "/", nid, P)
+            ref = po.preprocess(s, d, parts, nid, P)
+            assert np.array_equal(part.view()["rowIdx"], ref["rowIdx"])
