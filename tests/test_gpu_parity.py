@@ -213,6 +213,8 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
     ("parts_toy60_p2", [602, 128, 41]),
     ("parts_toy60_p4_hash", [33, 16, 7]),
     ("parts_toy97_p8_und", [20, 12, 9, 4]),
+    ("parts_toy97_p8_und", [300, 64, 64, 25]),     # BASELINE config 4 shape: Amazon GCN 3-layer, 8 partitions
+    ("parts_toy97_p8_und", [256, 48, 51]),         # BASELINE config 5 shape: Friendster GCN 2-layer, 8 partitions
 ])
 def test_gcn_epoch_vs_oracle(da, case, dims):
     """Whole forward+backward epoch, every named tensor, P partitions with halo."""
