@@ -65,7 +65,9 @@ def splitmix_uniform(seed, rows_global, cols, lo=-1.0, hi=1.0):
 def halo_selfcheck(ctx, g, da):
     """N > 1 only, before any timing: one forward and one backward halo exchange of rows
     that are a known function of the global vertex id; every received ghost row must be
-    the owner's row bit for bit (plan + pack + RCCL all-to-all-v + unpack end to end)."""
+    the owner's row bit for bit (plan + pack + RCCL all-to-all-v + unpack end to end).
+    Then the overlapped schedule (local-source blocks of the SpMM running under the
+    exchange) must give bit-identical aggregates to the sequential one."""
     ctx.fill_uniform(0, "h", 7, -1.0, 1.0, g["localToGlobal"])
     ctx.halo_exchange(1, da.FORWARD)
     ctx.sync()
@@ -74,6 +76,17 @@ def halo_selfcheck(ctx, g, da):
     ctx.halo_exchange(1, da.BACKWARD)
     ctx.sync()
     ok = ok and np.array_equal(ctx.download(0, "bg"), splitmix_uniform(9, g["dstGhost"], DIMS[1]))
+    res = {}
+    for overlap in (0, 1):
+        ctx.set_option("halo_overlap", overlap)
+        ctx.fill_uniform(0, "h", 7, -1.0, 1.0, g["localToGlobal"])
+        ctx.halo_exchange(1, da.FORWARD)
+        ctx.aggregate(1, da.FORWARD)          # consumes fg@1: split launch when overlap is on
+        ctx.halo_exchange(1, da.BACKWARD)
+        ctx.aggregate(1, da.BACKWARD)
+        ctx.sync()
+        res[overlap] = (ctx.download(1, "ah"), ctx.download(0, "aTg"))
+    ok = ok and np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     return bool(ok)
 
 
@@ -237,7 +250,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
-            "halo_selfcheck": halo_ok,
+            "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1),
             "setup_s": round(t_setup, 1),
         }
         print(json.dumps(out), flush=True)

@@ -168,6 +168,16 @@ int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const 
 static int ensure_blocked(dory_ctx *c, bool csc, int group);
 static int blk_group_for(dory_ctx *c, uint32_t ld);
 
+// Ghost rows of the last halo exchange land on the comm stream; with "halo_overlap" the
+// compute stream is only made to wait for them (event ev_b) by the first consumer.
+static int wait_halo(dory_ctx *c) {
+    if (c->halo_pending) {
+        HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+        c->halo_pending = false;
+    }
+    return DORY_OK;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------
@@ -199,6 +209,8 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
+    c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
+    c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
     return DORY_OK;
@@ -215,6 +227,7 @@ static void free_graph(dory_ctx *c) {
     free_blocked(&c->blkIn);
     free_blocked(&c->blkOut);
     c->blkIn_built = c->blkOut_built = false;
+    c->blkIn_na = c->blkOut_na = false;
     c->has_graph = false;
 }
 
@@ -270,6 +283,7 @@ int dory_sync(dory_ctx *c) {
     CHECK_CTX(c);
     HIPCK(c, hipStreamSynchronize(c->compute));
     HIPCK(c, hipStreamSynchronize(c->comm));
+    c->halo_pending = false;   // everything has landed
     return DORY_OK;
 }
 
@@ -461,6 +475,7 @@ static int download_dense(dory_ctx *c, const Tensor &t, float *host) {
 
 int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const float *host) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_upload: no tensor '%s' at layer %u", name ? name : "(null)", layer);
     if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
@@ -470,6 +485,7 @@ int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const floa
 
 int dory_tensor_download(dory_ctx *c, uint32_t layer, const char *name, float *host) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_download: no tensor '%s' at layer %u", name ? name : "(null)", layer);
     return download_dense(c, *t, host);
@@ -478,6 +494,7 @@ int dory_tensor_download(dory_ctx *c, uint32_t layer, const char *name, float *h
 int dory_tensor_fill_uniform(dory_ctx *c, uint32_t layer, const char *name, uint64_t seed, float lo,
                              float hi, const uint32_t *global_row_ids) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t) return fail(c, DORY_ERR_ARG, "tensor_fill: no tensor '%s' at layer %u", name ? name : "(null)", layer);
     uint32_t *ids = nullptr;
@@ -563,6 +580,14 @@ static int ensure_blocked(dory_ctx *c, bool csc, int group) {
     }
     if (!built) {
         const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
+        // K1b pays nb partial rows per output row: only worth it (and only affordable: the
+        // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
+        // hundred L2 windows at most.  Larger partitions keep K1.
+        const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u);
+        if (nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
+            (csc ? c->blkIn_na : c->blkOut_na) = true;
+            return DORY_OK;
+        }
         HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
                                c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute));
         B.row_bytes = (uint32_t)group * 16u;
@@ -603,7 +628,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         if (rc) return rc;
         BlockedAdj &B = csc ? c->blkIn : c->blkOut;
         const size_t need = blocked_partial_bytes(a, B);
-        if (B.nb > 0 && need <= ((size_t)48 << 30)) {
+        if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
             if (need > c->partial_bytes) {
                 HIPCK(c, hipStreamSynchronize(c->compute));
                 if (c->partial) hipFree(c->partial);
@@ -613,11 +638,27 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 c->partial_bytes = need;
             }
             Timed t(c, "spmm", c->compute);
-            HIPCK(c, launch_spmm_blocked(a, B, c->partial, group, row_scale, c->compute));
+            // source blocks that contain local rows only do not depend on the exchange in
+            // flight: they run first, the ghost blocks after the comm stream's event
+            const uint32_t nb_local = std::min(B.nb, c->N / B.SB);
+            const bool split = (c->halo_pending || c->opt["spmm_blk_force_split"]) && nb_local > 0 && nb_local < B.nb;
+            if (split) {
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, nb_local, c->compute));
+                if ((rc = wait_halo(c))) return rc;
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, nb_local, B.nb, c->compute));
+            } else {
+                if ((rc = wait_halo(c))) return rc;
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, B.nb, c->compute));
+            }
+            HIPCK(c, launch_spmm_blocked_reduce(a, B, c->partial, row_scale, c->compute));
             return DORY_OK;
         }
     }
     if (!val) return fail(c, DORY_ERR_ARG, "spmm: no edge values");
+    {
+        int rc = wait_halo(c);
+        if (rc) return rc;
+    }
     Timed t(c, "spmm", c->compute);
     HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
     return DORY_OK;
@@ -673,6 +714,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
 
 int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (!c->prealloc) return fail(c, DORY_ERR_ARG, "apply_vertex: preallocate first");
     if (layer >= c->L) return fail(c, DORY_ERR_ARG, "apply_vertex: layer %u out of range", layer);
     const uint32_t N = c->N, Fin = c->dims[layer], Fout = c->dims[layer + 1];
@@ -741,6 +783,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
 
 int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (!c->prealloc || c->gnn != DORY_GAT) {
         if (c->prealloc && c->gnn == DORY_GCN) return DORY_OK;  // applyEdgeGCN is a no-op (gcn_ops.cpp:364-366)
         return fail(c, DORY_ERR_ARG, "apply_edge: preallocate first");
@@ -783,6 +826,7 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
 
 int dory_predict_gat(dory_ctx *c, uint32_t layer) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (!c->prealloc || c->gnn != DORY_GAT || layer == 0 || layer > c->L)
         return fail(c, DORY_ERR_ARG, "predict_gat: bad state or layer");
     const uint32_t fl = layer - 1;
@@ -885,6 +929,7 @@ static int halo_tensors(dory_ctx *c, uint32_t layer, int dir, Tensor **src, Tens
 
 int dory_halo_pack(dory_ctx *c, uint32_t layer, int dir, float *send_buf) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
     if (rc) return rc;
@@ -897,6 +942,7 @@ int dory_halo_pack(dory_ctx *c, uint32_t layer, int dir, float *send_buf) {
 
 int dory_halo_unpack(dory_ctx *c, uint32_t layer, int dir, const float *recv_buf) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
     if (rc) return rc;
@@ -909,6 +955,7 @@ int dory_halo_unpack(dory_ctx *c, uint32_t layer, int dir, const float *recv_buf
 
 int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (c->numNodes == 1) return DORY_OK;  // no ghosts
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
@@ -951,9 +998,11 @@ int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
         NCCLCK(c, ncclGroupEnd());
         HIPCK(c, launch_scatter_rows(ghost->d, c->recv_buf, ghost->ld, w, p.d_recv_slots, p.recv_total, c->comm));
     }
-    // consumers on the compute stream wait for the ghosts
+    // consumers on the compute stream wait for the ghosts: at once, or (halo_overlap) when
+    // the first of them needs the ghost rows -- see wait_halo()
     HIPCK(c, hipEventRecord(c->ev_b, c->comm));
-    HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+    if (c->opt["halo_overlap"]) c->halo_pending = true;
+    else HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
     return DORY_OK;
 }
 
@@ -967,6 +1016,7 @@ int dory_adam_config(dory_ctx *c, float learning_rate) {
 
 int dory_weight_update(dory_ctx *c, uint32_t layer) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (!c->prealloc || layer >= c->L) return fail(c, DORY_ERR_ARG, "weight_update: bad state or layer");
     // AdamOptimizer::nextIteration (src/weight-server/AdamOptimizer.cpp:29-34)
     const float b1p = (float)std::pow((double)0.9f, (double)c->adam.epochs);

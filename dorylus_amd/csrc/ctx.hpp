@@ -66,6 +66,7 @@ struct dory_ctx {
     hipStream_t compute = nullptr, comm = nullptr;
     bool own_compute = false, own_comm = false;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;  // cross-stream ordering
+    bool halo_pending = false;  // ghosts of the last exchange are still landing (comm stream, ev_b)
 
     // model
     bool configured = false;
@@ -86,6 +87,7 @@ struct dory_ctx {
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
     bool blkIn_built = false, blkOut_built = false;
+    bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
     float *partial = nullptr;
@@ -146,6 +148,11 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);
 hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                          uint64_t nnz, uint32_t want_nb /*0 = auto*/, uint32_t row_bytes, BlockedAdj *out,
                          hipStream_t s);
+uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes);
+hipError_t launch_spmm_blocked_part(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, bool unit,
+                                    uint32_t b_lo, uint32_t b_hi, hipStream_t s);
+hipError_t launch_spmm_blocked_reduce(const SpmmArgs &a, const BlockedAdj &B, const float *partial,
+                                      const float *row_scale, hipStream_t s);
 void free_blocked(BlockedAdj *B);
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,

@@ -263,18 +263,23 @@ __global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, 
     }
 }
 
+// nb = multiple of 8 (one block per XCD per round).  Window SB*row_bytes: measured optimum
+// (profiles/r01_k1b_param_sweep.txt) is ~3.7 MB at 256-B rows and ~5 MB at 512-B rows -- a
+// little over the 4 MB L2 is fine (Infinity Cache backs it), shorter (block,row) segments
+// and more partial traffic are not.
+uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes) {
+    const uint64_t window = row_bytes >= 512 ? (uint64_t)5242880u : (uint64_t)3932160u;
+    uint32_t nb = 8;
+    if (want_nb) nb = (want_nb + 7) / 8 * 8;
+    else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > window && nb < (1u << 20)) nb += 8;
+    return nb;
+}
+
 hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                          uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, BlockedAdj *out, hipStream_t s) {
     BlockedAdj B{};
     if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
-    // nb = multiple of 8 (one block per XCD per round).  Window SB*row_bytes: measured
-    // optimum (profiles/r01_k1b_param_sweep.txt) is ~3.7 MB at 256-B rows and ~5 MB at
-    // 512-B rows -- a little over the 4 MB L2 is fine (Infinity Cache backs it), shorter
-    // (block,row) segments and more partial traffic are not.
-    const uint64_t window = row_bytes >= 512 ? (uint64_t)5242880u : (uint64_t)3932160u;
-    uint32_t nb = 8;
-    if (want_nb) nb = (want_nb + 7) / 8 * 8;
-    else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > window && nb < 4096) nb += 8;
+    const uint32_t nb = plan_blocks(NG, want_nb, row_bytes);
     B.nb = nb;
     B.SB = (NG + nb - 1) / nb;
     uint32_t *cnt = nullptr;
@@ -317,7 +322,8 @@ void free_blocked(BlockedAdj *B) {
 
 template <int GROUP, bool UNIT>
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAdj B, float *partial,
-                                                           uint32_t tiles, uint32_t rounds) {
+                                                           uint32_t tiles, uint32_t round0, uint32_t rounds,
+                                                           uint32_t b_lo, uint32_t b_hi) {
     constexpr int RPW = 64 / GROUP;
     constexpr int BLK_ITER = BLK_ROWS / (4 * RPW);
     const uint32_t id = blockIdx.x;
@@ -325,10 +331,10 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
     uint32_t k = id >> 3;
     const uint32_t tile = k % tiles;
     k /= tiles;
-    const uint32_t round = k % rounds;
+    const uint32_t round = round0 + k % rounds;
     const uint32_t slab = k / rounds;
     const uint32_t b = round * 8u + xcd;
-    if (b >= B.nb) return;
+    if (b < b_lo || b >= b_hi) return;   // this launch covers source blocks [b_lo, b_hi)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -435,33 +441,51 @@ size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B) {
     return (size_t)B.nb * a.N * a.ld * sizeof(float);
 }
 
-hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group,
-                               const float *row_scale, hipStream_t s) {
-    if (a.N == 0 || a.ld == 0) return hipSuccess;
-    if ((a.ld & 3) || B.nb == 0 || (group != 8 && group != 16 && group != 32)) return hipErrorInvalidValue;
+// partial sums of source blocks [b_lo, b_hi) (all slabs, all row tiles)
+hipError_t launch_spmm_blocked_part(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, bool unit,
+                                    uint32_t b_lo, uint32_t b_hi, hipStream_t s) {
+    if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
+    if ((a.ld & 3) || B.nb == 0 || b_hi > B.nb || (group != 8 && group != 16 && group != 32)) return hipErrorInvalidValue;
     const uint32_t nchunk = a.ld >> 2;
     const uint32_t slabs = (nchunk + group - 1) / group;
     const uint32_t tiles = (a.N + BLK_ROWS - 1) / BLK_ROWS;
-    const uint32_t rounds = (B.nb + 7) / 8;
+    const uint32_t round0 = b_lo / 8;
+    const uint32_t rounds = (b_hi + 7) / 8 - round0;
     const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 gr((uint32_t)grid), bl(256);
-    const bool unit = row_scale != nullptr;   // per-row factor: unweighted gather, scaled in the reduce
-#define LAUNCH_BLK(G)                                                                                           \
-    do {                                                                                                        \
-        if (unit) hipLaunchKernelGGL((spmm_blocked_kernel<G, true>), gr, bl, 0, s, a, B, partial, tiles, rounds);  \
-        else hipLaunchKernelGGL((spmm_blocked_kernel<G, false>), gr, bl, 0, s, a, B, partial, tiles, rounds);      \
+#define LAUNCH_BLK(G)                                                                                         \
+    do {                                                                                                      \
+        if (unit)                                                                                             \
+            hipLaunchKernelGGL((spmm_blocked_kernel<G, true>), gr, bl, 0, s, a, B, partial, tiles, round0,     \
+                               rounds, b_lo, b_hi);                                                           \
+        else                                                                                                  \
+            hipLaunchKernelGGL((spmm_blocked_kernel<G, false>), gr, bl, 0, s, a, B, partial, tiles, round0,    \
+                               rounds, b_lo, b_hi);                                                           \
     } while (0)
     if (group == 8) LAUNCH_BLK(8);
     else if (group == 16) LAUNCH_BLK(16);
     else LAUNCH_BLK(32);
 #undef LAUNCH_BLK
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// out = self + (row_scale *) sum_b partial[b]
+hipError_t launch_spmm_blocked_reduce(const SpmmArgs &a, const BlockedAdj &B, const float *partial,
+                                      const float *row_scale, hipStream_t s) {
+    if (a.N == 0 || a.ld == 0) return hipSuccess;
+    const uint32_t nchunk = a.ld >> 2;
     const size_t n = (size_t)a.N * nchunk;
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(spmm_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, row_scale);
     return hipGetLastError();
+}
+
+hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group,
+                               const float *row_scale, hipStream_t s) {
+    hipError_t e = launch_spmm_blocked_part(a, B, partial, group, row_scale != nullptr, 0, B.nb, s);
+    if (e != hipSuccess) return e;
+    return launch_spmm_blocked_reduce(a, B, partial, row_scale, s);
 }
 
 }  // namespace dory

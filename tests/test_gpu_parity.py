@@ -80,8 +80,10 @@ def test_aggregate_blocked_variant_vs_oracle(da, case, F):
         ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
         ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
         ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
-        for grp in (32, 16, 16):   # same group twice: the second pass reuses the blocked structure
+        for grp, split in ((32, 0), (16, 0), (16, 1), (32, 1)):   # split: local-source blocks launched apart
             ctx.set_option("spmm_blk_group", grp)
+            ctx.set_option("spmm_blk_force_split", split)
+            ctx.set_option("spmm_blk_nb", 8 * split)        # toy graphs: several blocks so that some are local-only
             ctx.aggregate(0, da.FORWARD)
             ctx.aggregate(1, da.BACKWARD)
             assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (case, r, F, grp)
