@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
 CSRC = dorylus_amd/csrc
-OBJS = $(CSRC)/abi.o $(CSRC)/spmm.o $(CSRC)/gemm.o $(CSRC)/elementwise.o
+OBJS = $(CSRC)/abi.o $(CSRC)/spmm.o $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/gat_mh.o
 HOSTOBJS = $(patsubst %.cpp,%.o,$(filter-out %_main.cpp,$(wildcard dorylus_amd/host/*.cpp)))
 GRAPHSERVER = dorylus_amd/graphserver
 INPUTS = dorylus_amd/dory-inputs

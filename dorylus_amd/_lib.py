@@ -22,10 +22,11 @@ SYMBOLS = [
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
     "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_ctx_describe",
+    "dory_gatmh_heads",
 ]
 
 FORWARD, BACKWARD = 0, 1
-GCN, GAT = 0, 1
+GCN, GAT, GATMH = 0, 1, 2
 
 
 class DoryError(RuntimeError):
@@ -75,6 +76,7 @@ def load():
         "dory_timing_reset": [vp],
         "dory_set_option": [vp, cp, C.c_int64],
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
+        "dory_gatmh_heads": [vp, vp],
         # include/dorylus_host.h
         "dory_partition_build": [vp, vp, u64, vp, u32, u32, u32, i32, C.POINTER(vp)],
         "dory_partition_build_from_files": [cp, u32, u32, i32, C.POINTER(vp)],
@@ -160,6 +162,12 @@ class Context:
             self.h, self.N, int(g["srcGhostCnt"]), int(g["dstGhostCnt"]), int(ri.size), _ptr(cp),
             _ptr(ri), _ptr(cv), int(ci.size), _ptr(rp), _ptr(ci), _ptr(rv), _ptr(nm)))
 
+    def gatmh_heads(self, heads):
+        h = np.ascontiguousarray(heads, np.uint32)
+        assert h.size == self.L
+        self.heads = [int(x) for x in h]
+        self._ck(self.lib.dory_gatmh_heads(self.h, _ptr(h)))
+
     def preallocate(self):
         self._ck(self.lib.dory_preallocate(self.h))
 
@@ -193,6 +201,10 @@ class Context:
 
     # -- weights ---------------------------------------------------------------------
     def _wshape(self, layer, name):
+        heads = getattr(self, "heads", None)
+        if heads is not None:   # multi-head GAT extension: the last layer keeps K_out copies of the class width
+            zw = self.dims[layer + 1] * (heads[layer] if layer == self.L - 1 else 1)
+            return (self.dims[layer], zw) if name == "w" else (zw, 1)
         return (self.dims[layer], self.dims[layer + 1]) if name == "w" else (self.dims[layer + 1], 1)
 
     def weight_set(self, layer, name, w):

@@ -290,7 +290,7 @@ int dory_sync(dory_ctx *c) {
 int dory_configure(dory_ctx *c, int gnn_type, uint32_t num_layers, const uint32_t *dims,
                    uint32_t global_vtx_cnt, uint32_t node_id, uint32_t num_nodes) {
     CHECK_CTX(c);
-    if (!dims || num_layers == 0 || (gnn_type != DORY_GCN && gnn_type != DORY_GAT) || num_nodes == 0 ||
+    if (!dims || num_layers == 0 || (gnn_type != DORY_GCN && gnn_type != DORY_GAT && gnn_type != DORY_GATMH) || num_nodes == 0 ||
         node_id >= num_nodes)
         return fail(c, DORY_ERR_ARG, "dory_configure: bad arguments");
     for (uint32_t i = 0; i <= num_layers; ++i)
@@ -301,7 +301,18 @@ int dory_configure(dory_ctx *c, int gnn_type, uint32_t num_layers, const uint32_
     c->globalV = global_vtx_cnt;
     c->nodeId = node_id;
     c->numNodes = num_nodes;
+    c->heads.assign(num_layers, 8);   // multi-head GAT extension defaults: 8 hidden heads, 1 output head
+    c->heads[num_layers - 1] = 1;
     c->configured = true;
+    return DORY_OK;
+}
+
+int dory_gatmh_heads(dory_ctx *c, const uint32_t *heads) {
+    CHECK_CTX(c);
+    if (!c->configured || c->gnn != DORY_GATMH || !heads) return fail(c, DORY_ERR_ARG, "gatmh_heads: configure with DORY_GATMH first");
+    for (uint32_t l = 0; l < c->L; ++l)
+        if (heads[l] == 0 || heads[l] > 64) return fail(c, DORY_ERR_ARG, "gatmh_heads: bad head count");
+    c->heads.assign(heads, heads + c->L);
     return DORY_OK;
 }
 
@@ -372,6 +383,27 @@ int dory_preallocate(dory_ctx *c) {
             mk(l - 1, "bg", c->Gdst, d[l]);
             mk(l - 1, "aTg", N, d[l]);
         }
+    } else if (c->gnn == DORY_GATMH) {  // extension (no reference counterpart): see dory_gatmh_heads
+        if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only in this version");
+        mk(0, "h", N, d[0]);
+        mk(L - 1, "lab", N, d[L]);
+        mk(L - 1, "logits", N, d[L]);
+        mk(L - 1, "grad", N, d[L]);
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t K = c->heads[l];
+            const bool last = l == L - 1;
+            const uint32_t zw = last ? d[l + 1] * K : d[l + 1];
+            const uint32_t D = zw / K;
+            if (zw % K || zw > 256 || (K > 1 && ((D & (D - 1)) || D > 64)))
+                return fail(c, DORY_ERR_ARG, "multi-head GAT: layer %u width %u does not split into %u heads (D power of two <= 64, K*D <= 256)", l, zw, K);
+            mk(l, "z", N, zw);
+            mk(l, "o", N, zw);
+            mk(l, "do", N, zw);
+            mk(l, "dz", N, zw);
+            for (const char *nm : {"el", "er", "m", "den", "t", "del", "der"}) mk(l, nm, N, K);
+            if (!last) mk(l + 1, "h", N, d[l + 1]);
+            if (l > 0) mk(l, "dh", N, d[l]);
+        }
     } else {  // Engine::preallocateGAT (engine/ops/gat_ops.cpp:27-115)
         mk(0, "h", N, d[0]);
         mk(L - 1, "lab", N, d[L]);
@@ -399,6 +431,15 @@ int dory_preallocate(dory_ctx *c) {
     }
     if (rc) return rc;
     for (uint32_t l = 0; l < L; ++l) {
+        if (c->gnn == DORY_GATMH) {
+            const uint32_t zw = l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1];
+            for (auto *tab : {&c->weights, &c->wgrads, &c->adam_m, &c->adam_v}) {
+                if ((rc = alloc_tensor(c, (*tab)[l]["w"], d[l], zw))) return rc;
+                if ((rc = alloc_tensor(c, (*tab)[l]["a_l"], zw, 1))) return rc;
+                if ((rc = alloc_tensor(c, (*tab)[l]["a_r"], zw, 1))) return rc;
+            }
+            continue;
+        }
         if ((rc = alloc_tensor(c, c->weights[l]["w"], d[l], d[l + 1]))) return rc;
         if ((rc = alloc_tensor(c, c->wgrads[l]["w"], d[l], d[l + 1]))) return rc;
         if ((rc = alloc_tensor(c, c->adam_m[l]["w"], d[l], d[l + 1]))) return rc;
@@ -412,7 +453,7 @@ int dory_preallocate(dory_ctx *c) {
     }
     c->adam.epochs = 1;
     HIPCK(c, hipStreamSynchronize(c->compute));
-    if (c->opt["spmm_variant"] == 1 && N > 0) {   // K1b: regroup the edges now, not inside the first epoch
+    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn != DORY_GATMH) {   // K1b: regroup the edges now, not inside the first epoch
         uint32_t minld = 0xFFFFFFFFu;
         for (uint32_t l = 0; l < L; ++l) {
             const uint32_t w = c->gnn == DORY_GCN ? (l == 0 ? d[0] : d[l]) : d[l + 1];
@@ -689,6 +730,47 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
     // Engine::aggregateGAT (gat_ops.cpp:173-243): tensors live at layer-1
     if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "aggregate GAT: layer %u out of range", layer);
     const uint32_t fl = layer - 1;
+    if (c->gnn == DORY_GATMH) {  // extension: edge softmax + weighted sum, and its backward
+        const uint32_t K = c->heads[fl];
+        const bool last = fl == c->L - 1;
+        NEED(z, fl, "z"); NEED(el, fl, "el"); NEED(er, fl, "er"); NEED(m, fl, "m"); NEED(den, fl, "den"); NEED(o, fl, "o");
+        const uint32_t D = z->cols / K;
+        if (dir == DORY_FORWARD) {
+            {
+                Timed t(c, "spmm", c->compute);
+                HIPCK(c, launch_gatmh_forward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, z->d, el->d, er->d, o->d,
+                                              m->d, den->d, c->compute));
+            }
+            Timed t(c, "loss", c->compute);
+            if (!last) {
+                NEED(hn, fl + 1, "h");
+                HIPCK(c, launch_gatmh_elu(c->N, o->cols, o->d, o->ld, hn->d, hn->ld, c->compute));
+            } else {
+                NEED(lg, fl, "logits");
+                HIPCK(c, launch_gatmh_head_mean(c->N, K, lg->cols, o->d, o->ld, lg->d, lg->ld, c->compute));
+            }
+            return DORY_OK;
+        }
+        NEED(dO, fl, "do"); NEED(dz, fl, "dz"); NEED(tt, fl, "t"); NEED(del, fl, "del"); NEED(der, fl, "der");
+        {
+            Timed t(c, "loss", c->compute);
+            if (last) {
+                NEED(gr, fl, "grad");
+                HIPCK(c, launch_gatmh_head_expand(c->N, K, gr->cols, gr->d, gr->ld, dO->d, dO->ld, c->compute));
+            } else {
+                NEED(dh, fl + 1, "dh");
+                HIPCK(c, launch_gatmh_elu_bwd(c->N, o->cols, dh->d, dh->ld, o->d, o->ld, dO->d, dO->ld, c->compute));
+            }
+        }
+        int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float));
+        if (rc) return rc;
+        Timed t(c, "spmm", c->compute);
+        HIPCK(c, launch_gatmh_backward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->rowPtr, c->colIdx, z->d, el->d,
+                                       er->d, m->d, den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d,
+                                       tt->d, del->d, der->d, dz->d, c->wgrads[fl]["a_l"].d, c->wgrads[fl]["a_r"].d,
+                                       c->scratch, c->scratch_bytes, c->compute));
+        return DORY_OK;
+    }
     NEED(z, fl, "z");
     NEED(fgz, fl, "fg_z");
     // dory_apply_edge leaves, next to the per-edge tensors "A" / "dA", the one value all
@@ -764,6 +846,19 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
         }
         return DORY_OK;
     }
+    if (c->gnn == DORY_GATMH) {  // extension: z = h*W ; backward dW = h^T dz, dh = dz W^T
+        NEED(hh, layer, "h");
+        NEED(z, layer, "z");
+        const uint32_t zw = z->cols;
+        if (dir == DORY_FORWARD) return gemm(c, 0, 0, N, zw, Fin, *hh, W, *z);
+        NEED(dz, layer, "dz");
+        if ((rc = gemm(c, 1, 0, Fin, zw, N, *hh, *dz, dW))) return rc;
+        if (layer != 0) {
+            NEED(dh, layer, "dh");
+            return gemm(c, 0, 1, N, Fin, zw, *dz, W, *dh);
+        }
+        return DORY_OK;
+    }
     // GAT
     Tensor *feats = layer == 0 ? find(c, 0, "h") : find(c, layer - 1, "ah");
     if (!feats) return fail(c, DORY_ERR_ARG, "apply_vertex GAT: input missing");
@@ -784,11 +879,20 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
 int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     CHECK_CTX(c);
     { int wrc = wait_halo(c); if (wrc) return wrc; }
-    if (!c->prealloc || c->gnn != DORY_GAT) {
+    if (!c->prealloc || c->gnn == DORY_GCN) {
         if (c->prealloc && c->gnn == DORY_GCN) return DORY_OK;  // applyEdgeGCN is a no-op (gcn_ops.cpp:364-366)
         return fail(c, DORY_ERR_ARG, "apply_edge: preallocate first");
     }
     if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "apply_edge: layer %u out of range", layer);
+    if (c->gnn == DORY_GATMH) {  // extension: attention scores per vertex and head; backward lives in aggregate
+        if (dir != DORY_FORWARD) return DORY_OK;
+        const uint32_t l0 = layer - 1, K = c->heads[l0];
+        NEED(z, l0, "z"); NEED(el, l0, "el"); NEED(er, l0, "er");
+        Timed t(c, "edge", c->compute);
+        HIPCK(c, launch_gatmh_scores(c->N, K, z->cols / K, z->d, z->ld, c->weights[l0]["a_l"].d, c->weights[l0]["a_r"].d,
+                                     el->d, er->d, el->ld, c->compute));
+        return DORY_OK;
+    }
     const uint32_t fl = layer - 1;  // "layer--; // YIFAN: fix this" (CPU_comm.cpp:33)
     const uint32_t F = c->dims[fl + 1];
     Tensor &a = c->weights[fl]["a_i"];
@@ -827,9 +931,15 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
 int dory_predict_gat(dory_ctx *c, uint32_t layer) {
     CHECK_CTX(c);
     { int wrc = wait_halo(c); if (wrc) return wrc; }
-    if (!c->prealloc || c->gnn != DORY_GAT || layer == 0 || layer > c->L)
+    if (!c->prealloc || c->gnn == DORY_GCN || layer == 0 || layer > c->L)
         return fail(c, DORY_ERR_ARG, "predict_gat: bad state or layer");
     const uint32_t fl = layer - 1;
+    if (c->gnn == DORY_GATMH) {
+        NEED(lg, fl, "logits"); NEED(lab, fl, "lab"); NEED(gr, fl, "grad");
+        Timed t(c, "loss", c->compute);
+        HIPCK(c, launch_softmax_sub(c->N, lg->cols, lg->d, lg->ld, lab->d, lab->ld, gr->d, gr->ld, c->compute));
+        return DORY_OK;
+    }
     // Engine::predictGAT (gat_ops.cpp:246-265).  The reference reads the edge tensor
     // "az" where it means the aggregated "ah" (SURVEY.md 0-6); we use "ah".
     NEED(ah, fl, "ah");
@@ -957,6 +1067,7 @@ int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
     CHECK_CTX(c);
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     if (c->numNodes == 1) return DORY_OK;  // no ghosts
+    if (c->gnn == DORY_GATMH) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only");
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
     if (rc) return rc;
@@ -1026,7 +1137,7 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
         const std::string &name = kv.first;
         // the reference only updates "w"; a_i updates are faked on the weight server
         // (src/weight-server/weightserver.cpp:112-116) -- keep a_i fixed as it does.
-        if (name != "w") continue;
+        if (name != "w" && c->gnn != DORY_GATMH) continue;   // the extension trains a_l / a_r too
         Tensor &w = kv.second;
         Tensor &g = c->wgrads[layer][name];
         const uint64_t n = (uint64_t)w.rows * w.ld;

@@ -74,6 +74,7 @@ struct dory_ctx {
     uint32_t L = 0;
     std::vector<uint32_t> dims;
     uint32_t globalV = 0, nodeId = 0, numNodes = 1;
+    std::vector<uint32_t> heads;   // multi-head GAT extension: heads per layer
 
     // graph (Graph, graph/graph.hpp:60-99)
     bool has_graph = false;
@@ -208,6 +209,26 @@ hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, co
                          hipStream_t s);
 hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *w,
                            float *partial, size_t partial_bytes, float *out, hipStream_t s);
+
+// multi-head GAT extension (csrc/gat_mh.hip)
+hipError_t launch_gatmh_scores(uint32_t N, uint32_t K, uint32_t D, const float *z, uint32_t ldz, const float *a_l,
+                               const float *a_r, float *el, float *er, uint32_t ldk, hipStream_t s);
+hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
+                                const uint32_t *rowidx, const float *z, const float *el, const float *er, float *o,
+                                float *m, float *den, hipStream_t s);
+hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
+                                 const uint32_t *rowidx, const uint64_t *rowptr, const uint32_t *colidx,
+                                 const float *z, const float *el, const float *er, const float *m, const float *den,
+                                 const float *d_o, const float *a_l, const float *a_r, float *t, float *del,
+                                 float *der, float *dz, float *da_l, float *da_r, float *scratch,
+                                 size_t scratch_bytes, hipStream_t s);
+hipError_t launch_gatmh_elu(uint64_t rows, uint32_t cols, const float *o, uint32_t ldo, float *h, uint32_t ldh, hipStream_t s);
+hipError_t launch_gatmh_elu_bwd(uint64_t rows, uint32_t cols, const float *dh, uint32_t lddh, const float *o,
+                                uint32_t ldo, float *d_o, uint32_t lddo, hipStream_t s);
+hipError_t launch_gatmh_head_mean(uint64_t rows, uint32_t K, uint32_t C, const float *o, uint32_t ldo, float *logits,
+                                  uint32_t ldl, hipStream_t s);
+hipError_t launch_gatmh_head_expand(uint64_t rows, uint32_t K, uint32_t C, const float *dl, uint32_t lddl, float *d_o,
+                                    uint32_t lddo, hipStream_t s);
 
 // K6 halo pack / unpack
 hipError_t launch_gather_rows(float *dst, const float *src, uint32_t ld, uint32_t cols,

@@ -1,0 +1,399 @@
+// gat_mh.hip -- multi-head GAT extension (BASELINE.json config 3 wording:
+// "8-head, per-edge attention softmax + weighted SpMM").  The reference has no such code
+// (its GAT is a single-head, softmax-free prototype: CPU_comm.cpp:190-242), so this is an
+// extension defined by oracle/gat_mh_oracle.py (float64; parity with the reference unpinned).
+//
+//   el[u,k] = <Z[u,k,:], a_l[k,:]>   er[v,k] = <Z[v,k,:], a_r[k,:]>
+//   s[e,k]  = LeakyReLU_0.2(el[src,k] + er[dst,k]);  alpha = softmax over in-edges of dst (+ self edge)
+//   O[v,k,:] = sum_e alpha[e,k] Z[src,k,:]
+//
+// Nothing of size E x K is ever stored: alpha is recomputed from el/er and the per-vertex
+// softmax statistics (m, den) wherever it is needed.  One wave per vertex; lane l owns
+// features l, l+64, ... of the K*D-wide row (coalesced 256-B gathers); per-head reductions
+// are xor-shuffles inside the D lanes that share a head.
+// Backward uses the identity  der = sum a*da*l' - t * sum a*l'  (t = sum a*da) so the
+// destination side needs a single sweep over the in-edges; the source side (CSR) gathers
+// dO, er, m, den, t of each destination and produces del and the alpha-weighted dZ.
+#include "ctx.hpp"
+
+namespace dory {
+
+constexpr float GATMH_SLOPE = 0.2f;
+constexpr int GATMH_MAXC = 4;   // K*D <= 256
+
+__device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : GATMH_SLOPE * x; }
+
+// sum over the D lanes of a head group (D power of two <= 64), result in every lane of the group
+__device__ __forceinline__ float head_sum(float v, int D) {
+    for (int o = 1; o < D; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// el / er: one thread per (vertex, head)
+__global__ void gatmh_scores_kernel(uint32_t N, uint32_t K, uint32_t D, const float *z, uint32_t ldz,
+                                    const float *a_l, const float *a_r, float *el, float *er, uint32_t ldk) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)N * K) return;
+    const uint32_t v = (uint32_t)(i / K), k = (uint32_t)(i % K);
+    const float *zr = z + (size_t)v * ldz + (size_t)k * D;
+    float sl = 0.f, sr = 0.f;
+    for (uint32_t d = 0; d < D; ++d) {
+        const float x = zr[d];
+        sl = fmaf(x, a_l[k * D + d], sl);
+        sr = fmaf(x, a_r[k * D + d], sr);
+    }
+    el[(size_t)v * ldk + k] = sl;
+    er[(size_t)v * ldk + k] = sr;
+}
+
+struct GatMhArgs {
+    uint32_t N, K, D, ld /*of z, o, do, dz*/, ldk /*of el, er, m, den, t, del, der*/;
+    const uint64_t *ptr;   // CSC (forward / dst pass) or CSR (src pass)
+    const uint32_t *idx;
+};
+
+// Forward: online softmax statistics, then alpha-weighted aggregation (self edge last).
+__global__ __launch_bounds__(256) void gatmh_forward_kernel(GatMhArgs a, const float *z, const float *el,
+                                                            const float *er, float *o, float *m_out,
+                                                            float *den_out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= a.N) return;
+    const uint32_t KD = a.K * a.D;
+    // phase-1 layout: lane = j*KP + k  (j: edge inside the chunk, k: head)
+    uint32_t KP = 1;
+    while (KP < a.K) KP <<= 1;
+    const uint32_t EPC = 64 / KP;
+    const uint32_t k1 = lane % KP, j1 = lane / KP;
+    const bool kok = k1 < a.K;
+    const float er_v = kok ? er[(size_t)v * a.ldk + k1] : 0.f;
+    const uint64_t e_beg = a.ptr[v], e_end = a.ptr[v + 1];   // edge e_end stands for the self edge
+    float m = -INFINITY, den = 0.f;
+    for (uint64_t e0 = e_beg; e0 <= e_end; e0 += EPC) {
+        const uint64_t e = e0 + j1;
+        if (e <= e_end && kok) {
+            const uint32_t u = e < e_end ? a.idx[e] : v;
+            const float s = lrelu02(el[(size_t)u * a.ldk + k1] + er_v);
+            const float mn = fmaxf(m, s);
+            den = den * __expf(m - mn) + __expf(s - mn);   // m = -inf first time: exp(-inf) = 0
+            m = mn;
+        }
+    }
+    for (uint32_t off = KP; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), d2 = __shfl_xor(den, off, 64);
+        const float mn = fmaxf(m, m2);
+        const float f1 = m == -INFINITY ? 0.f : __expf(m - mn), f2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        den = den * f1 + d2 * f2;
+        m = mn;
+    }
+    if (j1 == 0 && kok) {
+        m_out[(size_t)v * a.ldk + k1] = m;
+        den_out[(size_t)v * a.ldk + k1] = den;
+    }
+    // phase 2
+    int hsel[GATMH_MAXC];
+    float acc[GATMH_MAXC];
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        hsel[c] = f < KD ? (int)(f / a.D) : 0;
+        acc[c] = 0.f;
+    }
+    for (uint64_t e0 = e_beg; e0 <= e_end; e0 += EPC) {
+        const uint64_t e = e0 + j1;
+        uint32_t u = v;
+        float alpha = 0.f;
+        if (e <= e_end) {
+            u = e < e_end ? a.idx[e] : v;
+            if (kok) alpha = __expf(lrelu02(el[(size_t)u * a.ldk + k1] + er_v) - m) / den;
+        }
+        const uint32_t cnt = (uint32_t)min((uint64_t)EPC, e_end + 1 - e0);
+        for (uint32_t jj = 0; jj < cnt; ++jj) {
+            const uint32_t uj = (uint32_t)__shfl((int)u, jj * KP, 64);
+            const float *zr = z + (size_t)uj * a.ld;
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) {
+                const uint32_t f = lane + 64 * c;
+                const float al = __shfl(alpha, jj * KP + hsel[c], 64);
+                if (f < KD) acc[c] = fmaf(al, zr[f], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        if (f < KD) o[(size_t)v * a.ld + f] = acc[c];
+    }
+}
+
+// Backward, destination side (CSC): t[v,k] = sum a*da, der[v,k] = sum a*da*l' - t*sum a*l'
+__global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, const float *z, const float *el,
+                                                                 const float *er, const float *m_in,
+                                                                 const float *den_in, const float *d_o,
+                                                                 float *t_out, float *der_out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= a.N) return;
+    const uint32_t KD = a.K * a.D;
+    const int Dred = a.K == 1 ? 64 : (int)a.D;   // K == 1: the whole row is one head
+    int hsel[GATMH_MAXC];
+    float dov[GATMH_MAXC], erv[GATMH_MAXC], mv[GATMH_MAXC], idn[GATMH_MAXC];
+    float t[GATMH_MAXC], a1[GATMH_MAXC], a2[GATMH_MAXC];
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        const bool ok = f < KD;
+        hsel[c] = ok ? (int)(f / a.D) : 0;
+        dov[c] = ok ? d_o[(size_t)v * a.ld + f] : 0.f;
+        erv[c] = er[(size_t)v * a.ldk + hsel[c]];
+        mv[c] = m_in[(size_t)v * a.ldk + hsel[c]];
+        idn[c] = 1.f / den_in[(size_t)v * a.ldk + hsel[c]];
+        t[c] = a1[c] = a2[c] = 0.f;
+    }
+    const uint64_t e_beg = a.ptr[v], e_end = a.ptr[v + 1];
+    for (uint64_t e = e_beg; e <= e_end; ++e) {
+        const uint32_t u = e < e_end ? a.idx[e] : v;
+        const float *zr = z + (size_t)u * a.ld;
+        float prod[GATMH_MAXC];
+#pragma unroll
+        for (int c = 0; c < GATMH_MAXC; ++c) {
+            const uint32_t f = lane + 64 * c;
+            prod[c] = f < KD ? dov[c] * zr[f] : 0.f;
+        }
+        if (a.K == 1) {   // one head spans all chunks
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) s += prod[c];
+            s = head_sum(s, 64);
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = s;
+        } else {
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = head_sum(prod[c], Dred);
+        }
+#pragma unroll
+        for (int c = 0; c < GATMH_MAXC; ++c) {
+            const float pre = el[(size_t)u * a.ldk + hsel[c]] + erv[c];
+            const float al = __expf(lrelu02(pre) - mv[c]) * idn[c];
+            const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
+            t[c] = fmaf(al, prod[c], t[c]);
+            a1[c] = fmaf(al * prod[c], lp, a1[c]);
+            a2[c] = fmaf(al, lp, a2[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        if (f < KD && (f % a.D) == 0) {
+            t_out[(size_t)v * a.ldk + hsel[c]] = t[c];
+            der_out[(size_t)v * a.ldk + hsel[c]] = a1[c] - t[c] * a2[c];
+        }
+    }
+}
+
+// Backward, source side (CSR): del[u,k] = sum_out dpre, dz[u,:] = sum_out alpha * dO[dst,:]
+//                              + del*a_l + der*a_r  (finishing terms fused at the end)
+__global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, const float *z, const float *el,
+                                                                 const float *er, const float *m_in,
+                                                                 const float *den_in, const float *t_in,
+                                                                 const float *der_in, const float *d_o,
+                                                                 const float *a_l, const float *a_r,
+                                                                 float *del_out, float *dz) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= a.N) return;
+    const uint32_t KD = a.K * a.D;
+    const int Dred = a.K == 1 ? 64 : (int)a.D;
+    int hsel[GATMH_MAXC];
+    float zu[GATMH_MAXC], elu_[GATMH_MAXC], del[GATMH_MAXC], acc[GATMH_MAXC];
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        const bool ok = f < KD;
+        hsel[c] = ok ? (int)(f / a.D) : 0;
+        zu[c] = ok ? z[(size_t)u * a.ld + f] : 0.f;
+        elu_[c] = el[(size_t)u * a.ldk + hsel[c]];
+        del[c] = acc[c] = 0.f;
+    }
+    const uint64_t e_beg = a.ptr[u], e_end = a.ptr[u + 1];
+    for (uint64_t e = e_beg; e <= e_end; ++e) {
+        const uint32_t v = e < e_end ? a.idx[e] : u;
+        const float *dor = d_o + (size_t)v * a.ld;
+        float dov[GATMH_MAXC], prod[GATMH_MAXC];
+#pragma unroll
+        for (int c = 0; c < GATMH_MAXC; ++c) {
+            const uint32_t f = lane + 64 * c;
+            dov[c] = f < KD ? dor[f] : 0.f;
+            prod[c] = dov[c] * zu[c];
+        }
+        if (a.K == 1) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) s += prod[c];
+            s = head_sum(s, 64);
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = s;
+        } else {
+#pragma unroll
+            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = head_sum(prod[c], Dred);
+        }
+#pragma unroll
+        for (int c = 0; c < GATMH_MAXC; ++c) {
+            const size_t vk = (size_t)v * a.ldk + hsel[c];
+            const float pre = elu_[c] + er[vk];
+            const float al = __expf(lrelu02(pre) - m_in[vk]) / den_in[vk];
+            const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
+            del[c] = fmaf(al * (prod[c] - t_in[vk]), lp, del[c]);
+            acc[c] = fmaf(al, dov[c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GATMH_MAXC; ++c) {
+        const uint32_t f = lane + 64 * c;
+        if (f < KD) {
+            const float dr = der_in[(size_t)u * a.ldk + hsel[c]];
+            dz[(size_t)u * a.ld + f] = acc[c] + del[c] * a_l[f] + dr * a_r[f];
+            if ((f % a.D) == 0) del_out[(size_t)u * a.ldk + hsel[c]] = del[c];
+        }
+    }
+}
+
+// da[f] = sum_u w[u, f/D] * Z[u,f]   (two stages, deterministic)
+__global__ __launch_bounds__(256) void gatmh_dattn_partial_kernel(uint32_t N, uint32_t KD, uint32_t D,
+                                                                  const float *z, uint32_t ld, const float *w,
+                                                                  uint32_t ldk, float *partial,
+                                                                  uint32_t rows_per_block) {
+    const uint32_t r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (uint32_t f = threadIdx.x; f < KD; f += 256) {
+        const uint32_t k = f / D;
+        float s = 0.f;
+        for (uint32_t u = r0; u < r1; ++u) s = fmaf(w[(size_t)u * ldk + k], z[(size_t)u * ld + f], s);
+        partial[(size_t)blockIdx.x * KD + f] = s;
+    }
+}
+__global__ void gatmh_colsum_final_kernel(uint32_t F, const float *partial, uint32_t nb, float *out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F) return;
+    float s = 0.f;
+    for (uint32_t b = 0; b < nb; ++b) s += partial[(size_t)b * F + j];
+    out[j] = s;
+}
+
+// h = ELU(o); do = dh * ELU'(o); logits = mean_k o[:,k,:]; do = expand(dlogits) / K
+__global__ void gatmh_elu_kernel(uint64_t rows, uint32_t cols, const float *o, uint32_t ldo, float *h, uint32_t ldh) {
+    const uint64_t n = rows * cols;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / cols;
+        const uint32_t c = (uint32_t)(i % cols);
+        const float x = o[r * ldo + c];
+        h[r * ldh + c] = x > 0.f ? x : expm1f(x);
+    }
+}
+__global__ void gatmh_elu_bwd_kernel(uint64_t rows, uint32_t cols, const float *dh, uint32_t lddh, const float *o,
+                                     uint32_t ldo, float *d_o, uint32_t lddo) {
+    const uint64_t n = rows * cols;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / cols;
+        const uint32_t c = (uint32_t)(i % cols);
+        const float x = o[r * ldo + c];
+        d_o[r * lddo + c] = dh[r * lddh + c] * (x > 0.f ? 1.f : __expf(x));
+    }
+}
+__global__ void gatmh_head_mean_kernel(uint64_t rows, uint32_t K, uint32_t C, const float *o, uint32_t ldo,
+                                       float *logits, uint32_t ldl) {
+    const uint64_t n = rows * C;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / C;
+        const uint32_t c = (uint32_t)(i % C);
+        float s = 0.f;
+        for (uint32_t k = 0; k < K; ++k) s += o[r * ldo + k * C + c];
+        logits[r * ldl + c] = s / (float)K;
+    }
+}
+__global__ void gatmh_head_expand_kernel(uint64_t rows, uint32_t K, uint32_t C, const float *dl, uint32_t lddl,
+                                         float *d_o, uint32_t lddo) {
+    const uint64_t n = rows * K * C;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / (K * C);
+        const uint32_t c = (uint32_t)(i % C);
+        d_o[r * lddo + (uint32_t)(i % (K * C))] = dl[r * lddl + c] / (float)K;
+    }
+}
+
+static int grid_for(uint64_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+hipError_t launch_gatmh_scores(uint32_t N, uint32_t K, uint32_t D, const float *z, uint32_t ldz, const float *a_l,
+                               const float *a_r, float *el, float *er, uint32_t ldk, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    const uint64_t n = (uint64_t)N * K;
+    hipLaunchKernelGGL(gatmh_scores_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, N, K, D, z, ldz, a_l, a_r, el, er, ldk);
+    return hipGetLastError();
+}
+
+static bool gatmh_shape_ok(uint32_t K, uint32_t D) {
+    if (K == 0 || D == 0 || K > 64 || (uint64_t)K * D > 64 * GATMH_MAXC) return false;
+    if (K == 1) return true;
+    return (D & (D - 1)) == 0 && D <= 64;   // per-head reductions are xor-shuffles inside D lanes
+}
+
+hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
+                                const uint32_t *rowidx, const float *z, const float *el, const float *er, float *o,
+                                float *m, float *den, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    if (!gatmh_shape_ok(K, D)) return hipErrorInvalidValue;
+    GatMhArgs a{N, K, D, ld, ldk, colptr, rowidx};
+    hipLaunchKernelGGL(gatmh_forward_kernel, dim3((N + 3) / 4), dim3(256), 0, s, a, z, el, er, o, m, den);
+    return hipGetLastError();
+}
+
+hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
+                                 const uint32_t *rowidx, const uint64_t *rowptr, const uint32_t *colidx,
+                                 const float *z, const float *el, const float *er, const float *m, const float *den,
+                                 const float *d_o, const float *a_l, const float *a_r, float *t, float *del,
+                                 float *der, float *dz, float *da_l, float *da_r, float *scratch,
+                                 size_t scratch_bytes, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    if (!gatmh_shape_ok(K, D)) return hipErrorInvalidValue;
+    GatMhArgs ac{N, K, D, ld, ldk, colptr, rowidx};
+    GatMhArgs ar{N, K, D, ld, ldk, rowptr, colidx};
+    hipLaunchKernelGGL(gatmh_backward_dst_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ac, z, el, er, m, den, d_o, t, der);
+    hipLaunchKernelGGL(gatmh_backward_src_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ar, z, el, er, m, den, t, der,
+                       d_o, a_l, a_r, del, dz);
+    const uint32_t KD = K * D;
+    uint32_t nb = 1024;
+    while (nb > 1 && (size_t)nb * KD * sizeof(float) > scratch_bytes) nb >>= 1;
+    uint32_t rpb = (N + nb - 1) / nb;
+    if (rpb == 0) rpb = 1;
+    nb = (N + rpb - 1) / rpb;
+    hipLaunchKernelGGL(gatmh_dattn_partial_kernel, dim3(nb), dim3(256), 0, s, N, KD, D, z, ld, del, ldk, scratch, rpb);
+    hipLaunchKernelGGL(gatmh_colsum_final_kernel, dim3((KD + 255) / 256), dim3(256), 0, s, KD, scratch, nb, da_l);
+    hipLaunchKernelGGL(gatmh_dattn_partial_kernel, dim3(nb), dim3(256), 0, s, N, KD, D, z, ld, der, ldk, scratch, rpb);
+    hipLaunchKernelGGL(gatmh_colsum_final_kernel, dim3((KD + 255) / 256), dim3(256), 0, s, KD, scratch, nb, da_r);
+    return hipGetLastError();
+}
+
+hipError_t launch_gatmh_elu(uint64_t rows, uint32_t cols, const float *o, uint32_t ldo, float *h, uint32_t ldh, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(gatmh_elu_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, s, rows, cols, o, ldo, h, ldh);
+    return hipGetLastError();
+}
+hipError_t launch_gatmh_elu_bwd(uint64_t rows, uint32_t cols, const float *dh, uint32_t lddh, const float *o,
+                                uint32_t ldo, float *d_o, uint32_t lddo, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(gatmh_elu_bwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, s, rows, cols, dh, lddh, o, ldo, d_o, lddo);
+    return hipGetLastError();
+}
+hipError_t launch_gatmh_head_mean(uint64_t rows, uint32_t K, uint32_t C, const float *o, uint32_t ldo, float *logits,
+                                  uint32_t ldl, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(gatmh_head_mean_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, rows, K, C, o, ldo, logits, ldl);
+    return hipGetLastError();
+}
+hipError_t launch_gatmh_head_expand(uint64_t rows, uint32_t K, uint32_t C, const float *dl, uint32_t lddl, float *d_o,
+                                    uint32_t lddo, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(gatmh_head_expand_kernel, dim3(grid_for(rows * K * C)), dim3(256), 0, s, rows, K, C, dl, lddl, d_o, lddo);
+    return hipGetLastError();
+}
+
+}  // namespace dory

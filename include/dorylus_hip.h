@@ -43,7 +43,9 @@ enum dory_status {
 };
 
 enum dory_dir { DORY_FORWARD = 0, DORY_BACKWARD = 1 }; /* PROP_TYPE, common/utils.hpp:46 */
-enum dory_gnn { DORY_GCN = 0, DORY_GAT = 1 };          /* GNN,       common/utils.hpp:48 */
+enum dory_gnn { DORY_GCN = 0, DORY_GAT = 1,            /* GNN,       common/utils.hpp:48 */
+                DORY_GATMH = 2 };  /* extension, not in the reference: multi-head GAT with per-edge
+                                      attention softmax (BASELINE config 3 wording) */
 
 /* ---- lifetime ---------------------------------------------------------------
  * Replaces ComputingUnit::getInstance / ComputingServer construction
@@ -64,6 +66,16 @@ int dory_sync(dory_ctx *ctx); /* wait for both streams (NodeManager::barrier's l
 int dory_configure(dory_ctx *ctx, int gnn_type, uint32_t num_layers,
                    const uint32_t *dims, uint32_t global_vtx_cnt,
                    uint32_t node_id, uint32_t num_nodes);
+
+/* Multi-head GAT extension only (gnn_type == DORY_GATMH): heads per layer (num_layers
+ * entries; default 8 for hidden layers, 1 for the last).  Hidden layer l concatenates its
+ * heads (dims[l+1] = K*D, D a power of two <= 64, K*D <= 256) and applies ELU; the last layer
+ * averages its heads into dims[L] logits.  Call between dory_configure and dory_preallocate.
+ * Tensors: h z el er m den o do dz t del der (+ logits grad lab at L-1), weights w a_l a_r.
+ * Stage mapping: apply_vertex fwd = z=h*W; apply_edge fwd = el,er; aggregate fwd = edge softmax
+ * + weighted sum (+ELU / head mean); predict_gat = softmax - label; aggregate bwd = attention
+ * backward (dz, da_l, da_r); apply_vertex bwd = dW, dh.  Single partition only in this version. */
+int dory_gatmh_heads(dory_ctx *ctx, const uint32_t *heads);
 
 /* Upload one partition's adjacency, exactly the arrays of Graph
  * (graph/graph.hpp:60-99): forwardAdj (CSC over destination columns, in-edges)

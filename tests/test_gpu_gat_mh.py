@@ -1,0 +1,83 @@
+"""Multi-head GAT extension (no reference counterpart; parity unpinned): the HIP path
+through the C-ABI and the C++ Engine against oracle/gat_mh_oracle.py (float64, pinned by
+finite differences in tests/test_oracle_gat_mh.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.mark.parametrize("dims,heads,V,E", [
+    ([24, 32, 8], [4, 2], 200, 1500),        # 4 heads x 8, two output heads (of 8 classes) averaged
+    ([40, 128, 41], [8, 1], 300, 4000),      # the Reddit layer shape: 8 heads x 16 -> 41 classes
+    ([16, 64, 7], [1, 1], 150, 900),         # single head: reductions span the whole row
+])
+def test_gat_mh_epoch_vs_oracle(dims, heads, V, E):
+    import dorylus_amd as da
+    import gat_mh_oracle as go
+    import partition_oracle as po
+    from helpers import rel_err
+    rng = np.random.default_rng(len(dims) + V)
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    s[:40], d[:40] = 3, rng.integers(0, V, 40)            # a hub source
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    params = []
+    for l in range(2):
+        zw = dims[l + 1] * (heads[l] if l == 1 else 1)
+        params.append([(rng.standard_normal((dims[l], zw)) / np.sqrt(dims[l])).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32)])
+    ctx = da.Context(0)
+    ctx.configure(da.GATMH, dims, V)
+    ctx.gatmh_heads(heads)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    ctx.upload(0, "h", X)
+    ctx.labels_upload(labels)
+    for l, (W, al, ar) in enumerate(params):
+        ctx.weight_set(l, "w", W)
+        ctx.weight_set(l, "a_l", al)
+        ctx.weight_set(l, "a_r", ar)
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(1)
+    fws, Hs, loss, dlogits, grads = go.epoch(g, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
+    for l in range(2):
+        assert rel_err(ctx.download(l, "z"), fws[l]["Z"]) < RTOL, (l, "z")
+        assert rel_err(ctx.download(l, "el"), fws[l]["el"]) < RTOL, (l, "el")
+        assert rel_err(ctx.download(l, "er"), fws[l]["er"]) < RTOL, (l, "er")
+        assert rel_err(ctx.download(l, "o"), fws[l]["O"]) < RTOL, (l, "o")
+        assert rel_err(ctx.download(l, "t"), grads[l]["t"]) < 5e-4, (l, "t")
+        assert rel_err(ctx.download(l, "del"), grads[l]["d_el"]) < 5e-4, (l, "del")
+        assert rel_err(ctx.download(l, "der"), grads[l]["d_er"]) < 5e-4, (l, "der")
+        assert rel_err(ctx.download(l, "dz"), grads[l]["dZ"]) < 5e-4, (l, "dz")
+        assert rel_err(ctx.weight_grad_get(l, "w"), grads[l]["dW"]) < 5e-4, (l, "dW")
+        assert rel_err(ctx.weight_grad_get(l, "a_l").ravel(), grads[l]["da_l"]) < 5e-4, (l, "da_l")
+        assert rel_err(ctx.weight_grad_get(l, "a_r").ravel(), grads[l]["da_r"]) < 5e-4, (l, "da_r")
+    assert rel_err(ctx.download(1, "logits"), Hs[2]) < RTOL
+    assert rel_err(ctx.download(1, "grad"), dlogits) < RTOL
+    assert rel_err(ctx.download(1, "h"), Hs[1]) < RTOL
+    # the softmax statistics really normalise: sum_e alpha = 1  <=>  den = sum exp(s - m)
+    assert np.all(ctx.download(0, "den") >= 1.0 - 1e-5)
+    # every parameter took an Adam step
+    for l in range(2):
+        for nm, p in zip(("w", "a_l", "a_r"), params[l]):
+            assert not np.array_equal(ctx.weight_get(l, nm).reshape(p.shape), p)
+    eng.close()
+    ctx.close()
+
+
+def test_gat_mh_rejects_bad_shapes():
+    import dorylus_amd as da
+    import partition_oracle as po
+    g = po.preprocess(np.array([0, 1]), np.array([1, 2]), np.zeros(4, np.int64), 0, 1)
+    ctx = da.Context(0)
+    ctx.configure(da.GATMH, [8, 30, 3], 4)
+    ctx.gatmh_heads([3, 1])                 # 30 / 3 = 10: not a power of two
+    ctx.graph_upload(g)
+    with pytest.raises(da.DoryError):
+        ctx.preallocate()
+    ctx.close()
