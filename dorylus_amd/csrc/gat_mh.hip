@@ -19,7 +19,7 @@
 namespace dory {
 
 constexpr float GATMH_SLOPE = 0.2f;
-constexpr int GATMH_MAXC = 4;   // K*D <= 256
+constexpr int GATMH_MAXC = 4;   // K*D <= 256 (kernels are instantiated for 1, 2 or 4 chunks of 64 floats)
 
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : GATMH_SLOPE * x; }
 
@@ -53,6 +53,7 @@ struct GatMhArgs {
 };
 
 // Forward: online softmax statistics, then alpha-weighted aggregation (self edge last).
+template <int NC>
 __global__ __launch_bounds__(256) void gatmh_forward_kernel(GatMhArgs a, const float *z, const float *el,
                                                             const float *er, float *o, float *m_out,
                                                             float *den_out) {
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(256) void gatmh_forward_kernel(GatMhArgs a, const f
         den_out[(size_t)v * a.ldk + k1] = den;
     }
     // phase 2
-    int hsel[GATMH_MAXC];
-    float acc[GATMH_MAXC];
+    int hsel[NC];
+    float acc[NC];
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         hsel[c] = f < KD ? (int)(f / a.D) : 0;
         acc[c] = 0.f;
@@ -108,25 +109,37 @@ __global__ __launch_bounds__(256) void gatmh_forward_kernel(GatMhArgs a, const f
             if (kok) alpha = __expf(lrelu02(el[(size_t)u * a.ldk + k1] + er_v) - m) / den;
         }
         const uint32_t cnt = (uint32_t)min((uint64_t)EPC, e_end + 1 - e0);
-        for (uint32_t jj = 0; jj < cnt; ++jj) {
-            const uint32_t uj = (uint32_t)__shfl((int)u, jj * KP, 64);
-            const float *zr = z + (size_t)uj * a.ld;
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {   // 4 source rows in flight; dead slots carry alpha = 0
+            float zz[4][NC], al[4][NC];
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) {
-                const uint32_t f = lane + 64 * c;
-                const float al = __shfl(alpha, jj * KP + hsel[c], 64);
-                if (f < KD) acc[c] = fmaf(al, zr[f], acc[c]);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t jj = min(j0 + q, cnt - 1);
+                const bool live = j0 + q < cnt;
+                const uint32_t uj = (uint32_t)__shfl((int)u, jj * KP, 64);
+                const float *zr = z + (size_t)uj * a.ld;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t f = lane + 64 * c;
+                    const float w = __shfl(alpha, jj * KP + hsel[c], 64);
+                    al[q][c] = live ? w : 0.f;
+                    zz[q][c] = f < KD ? zr[f] : 0.f;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fmaf(al[q][c], zz[q][c], acc[c]);
         }
     }
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         if (f < KD) o[(size_t)v * a.ld + f] = acc[c];
     }
 }
 
 // Backward, destination side (CSC): t[v,k] = sum a*da, der[v,k] = sum a*da*l' - t*sum a*l'
+template <int NC>
 __global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, const float *z, const float *el,
                                                                  const float *er, const float *m_in,
                                                                  const float *den_in, const float *d_o,
@@ -136,11 +149,11 @@ __global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, co
     if (v >= a.N) return;
     const uint32_t KD = a.K * a.D;
     const int Dred = a.K == 1 ? 64 : (int)a.D;   // K == 1: the whole row is one head
-    int hsel[GATMH_MAXC];
-    float dov[GATMH_MAXC], erv[GATMH_MAXC], mv[GATMH_MAXC], idn[GATMH_MAXC];
-    float t[GATMH_MAXC], a1[GATMH_MAXC], a2[GATMH_MAXC];
+    int hsel[NC];
+    float dov[NC], erv[NC], mv[NC], idn[NC];
+    float t[NC], a1[NC], a2[NC];
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         const bool ok = f < KD;
         hsel[c] = ok ? (int)(f / a.D) : 0;
@@ -154,25 +167,25 @@ __global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, co
     for (uint64_t e = e_beg; e <= e_end; ++e) {
         const uint32_t u = e < e_end ? a.idx[e] : v;
         const float *zr = z + (size_t)u * a.ld;
-        float prod[GATMH_MAXC];
+        float prod[NC];
 #pragma unroll
-        for (int c = 0; c < GATMH_MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const uint32_t f = lane + 64 * c;
             prod[c] = f < KD ? dov[c] * zr[f] : 0.f;
         }
         if (a.K == 1) {   // one head spans all chunks
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) s += prod[c];
+            for (int c = 0; c < NC; ++c) s += prod[c];
             s = head_sum(s, 64);
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = s;
+            for (int c = 0; c < NC; ++c) prod[c] = s;
         } else {
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = head_sum(prod[c], Dred);
+            for (int c = 0; c < NC; ++c) prod[c] = head_sum(prod[c], Dred);
         }
 #pragma unroll
-        for (int c = 0; c < GATMH_MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const float pre = el[(size_t)u * a.ldk + hsel[c]] + erv[c];
             const float al = __expf(lrelu02(pre) - mv[c]) * idn[c];
             const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, co
         }
     }
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         if (f < KD && (f % a.D) == 0) {
             t_out[(size_t)v * a.ldk + hsel[c]] = t[c];
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(256) void gatmh_backward_dst_kernel(GatMhArgs a, co
 
 // Backward, source side (CSR): del[u,k] = sum_out dpre, dz[u,:] = sum_out alpha * dO[dst,:]
 //                              + del*a_l + der*a_r  (finishing terms fused at the end)
+template <int NC>
 __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, const float *z, const float *el,
                                                                  const float *er, const float *m_in,
                                                                  const float *den_in, const float *t_in,
@@ -204,10 +218,10 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, co
     if (u >= a.N) return;
     const uint32_t KD = a.K * a.D;
     const int Dred = a.K == 1 ? 64 : (int)a.D;
-    int hsel[GATMH_MAXC];
-    float zu[GATMH_MAXC], elu_[GATMH_MAXC], del[GATMH_MAXC], acc[GATMH_MAXC];
+    int hsel[NC];
+    float zu[NC], elu_[NC], del[NC], acc[NC];
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         const bool ok = f < KD;
         hsel[c] = ok ? (int)(f / a.D) : 0;
@@ -219,9 +233,9 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, co
     for (uint64_t e = e_beg; e <= e_end; ++e) {
         const uint32_t v = e < e_end ? a.idx[e] : u;
         const float *dor = d_o + (size_t)v * a.ld;
-        float dov[GATMH_MAXC], prod[GATMH_MAXC];
+        float dov[NC], prod[NC];
 #pragma unroll
-        for (int c = 0; c < GATMH_MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const uint32_t f = lane + 64 * c;
             dov[c] = f < KD ? dor[f] : 0.f;
             prod[c] = dov[c] * zu[c];
@@ -229,16 +243,16 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, co
         if (a.K == 1) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) s += prod[c];
+            for (int c = 0; c < NC; ++c) s += prod[c];
             s = head_sum(s, 64);
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = s;
+            for (int c = 0; c < NC; ++c) prod[c] = s;
         } else {
 #pragma unroll
-            for (int c = 0; c < GATMH_MAXC; ++c) prod[c] = head_sum(prod[c], Dred);
+            for (int c = 0; c < NC; ++c) prod[c] = head_sum(prod[c], Dred);
         }
 #pragma unroll
-        for (int c = 0; c < GATMH_MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const size_t vk = (size_t)v * a.ldk + hsel[c];
             const float pre = elu_[c] + er[vk];
             const float al = __expf(lrelu02(pre) - m_in[vk]) / den_in[vk];
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, co
         }
     }
 #pragma unroll
-    for (int c = 0; c < GATMH_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t f = lane + 64 * c;
         if (f < KD) {
             const float dr = der_in[(size_t)u * a.ldk + hsel[c]];
@@ -342,7 +356,10 @@ hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld,
     if (N == 0) return hipSuccess;
     if (!gatmh_shape_ok(K, D)) return hipErrorInvalidValue;
     GatMhArgs a{N, K, D, ld, ldk, colptr, rowidx};
-    hipLaunchKernelGGL(gatmh_forward_kernel, dim3((N + 3) / 4), dim3(256), 0, s, a, z, el, er, o, m, den);
+    const uint32_t KD = K * D;
+    if (KD <= 64) hipLaunchKernelGGL(gatmh_forward_kernel<1>, dim3((N + 3) / 4), dim3(256), 0, s, a, z, el, er, o, m, den);
+    else if (KD <= 128) hipLaunchKernelGGL(gatmh_forward_kernel<2>, dim3((N + 3) / 4), dim3(256), 0, s, a, z, el, er, o, m, den);
+    else hipLaunchKernelGGL(gatmh_forward_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, s, a, z, el, er, o, m, den);
     return hipGetLastError();
 }
 
@@ -356,10 +373,18 @@ hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld
     if (!gatmh_shape_ok(K, D)) return hipErrorInvalidValue;
     GatMhArgs ac{N, K, D, ld, ldk, colptr, rowidx};
     GatMhArgs ar{N, K, D, ld, ldk, rowptr, colidx};
-    hipLaunchKernelGGL(gatmh_backward_dst_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ac, z, el, er, m, den, d_o, t, der);
-    hipLaunchKernelGGL(gatmh_backward_src_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ar, z, el, er, m, den, t, der,
-                       d_o, a_l, a_r, del, dz);
     const uint32_t KD = K * D;
+    const dim3 gr((N + 3) / 4), bl(256);
+#define GATMH_BWD(NC)                                                                                                  \
+    do {                                                                                                               \
+        hipLaunchKernelGGL(gatmh_backward_dst_kernel<NC>, gr, bl, 0, s, ac, z, el, er, m, den, d_o, t, der);            \
+        hipLaunchKernelGGL(gatmh_backward_src_kernel<NC>, gr, bl, 0, s, ar, z, el, er, m, den, t, der, d_o, a_l, a_r,   \
+                           del, dz);                                                                                   \
+    } while (0)
+    if (KD <= 64) GATMH_BWD(1);
+    else if (KD <= 128) GATMH_BWD(2);
+    else GATMH_BWD(4);
+#undef GATMH_BWD
     uint32_t nb = 1024;
     while (nb > 1 && (size_t)nb * KD * sizeof(float) > scratch_bytes) nb >>= 1;
     uint32_t rpb = (N + nb - 1) / nb;
