@@ -141,6 +141,12 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -- setup -----------------------------------------------------------------
     def configure(self, gnn, dims, global_vtx_cnt, node_id=0, num_nodes=1):
         d = np.ascontiguousarray(dims, dtype=np.uint32)

@@ -465,6 +465,16 @@ int dory_preallocate(dory_ctx *c) {
         if (minld >= 32) {
             if ((rc = ensure_blocked(c, true, group))) return rc;
             if ((rc = ensure_blocked(c, false, group))) return rc;
+            // the partial-sum buffer too, so that no allocation happens inside an epoch
+            const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+            const size_t need = (size_t)nbmax * N * maxld * sizeof(float);
+            if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
+                if (c->partial) hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
         }
     }
     c->prealloc = true;
