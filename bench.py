@@ -28,6 +28,12 @@ sys.path.insert(0, ROOT)
 REDDIT_V = 232965
 REDDIT_E = 114615892
 DIMS = [602, 128, 41]          # run/reddit.config
+# other BASELINE.json configs (parity/scale cases, not the headline line): SURVEY.md 8(d) shapes
+WORKLOADS = {
+    "reddit": (REDDIT_V, REDDIT_E, [602, 128, 41]),
+    "amazon": (9430088, 231594310, [300, 64, 64, 25]),          # config 4: Amazon GCN 3-layer
+    "friendster": (65608366, 3612134270, [256, 48, 51]),        # config 5 (use --emulate r/8: one rank's partition)
+}
 
 
 def synth_edges(kind, V, E, seed=42):
@@ -102,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw"])
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
+    ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS),
+                    help="graph/model shape; anything but reddit is a scale test, not the BASELINE metric line")
     ap.add_argument("--gnn", default="gcn", choices=["gcn", "gat", "gatmh"],
                     help="gat = the reference's GAT prototype (BASELINE config 3's weighted-SpMM part); gatmh = the "
                          "8-head per-edge-softmax extension (config 3's wording; no reference oracle); not the headline metric")
@@ -129,8 +137,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import dorylus_amd as da
 
-    V = REDDIT_V
-    E_target = int(REDDIT_E * args.scale)
+    global DIMS
+    V, E_full, DIMS = WORKLOADS[args.workload]
+    E_target = int(E_full * args.scale)
     t_setup = time.time()
     src, dst = synth_edges(args.graph, V, E_target)
     pw, pr = world, rank
@@ -201,7 +210,8 @@ def main():
     else:
         E_in, E_out = nnz_in, nnz_out
     ms_per_step = elapsed * 1e3 / args.steps
-    edges_per_epoch = 2 * E_in + E_out                       # fwd L0, fwd L1 (CSC) + bwd L1 (CSR)
+    nl = len(DIMS) - 1
+    edges_per_epoch = nl * E_in + (nl - 1) * E_out           # L forward (CSC) + L-1 backward (CSR) aggregations
     if gat:                                                  # 2 fwd (CSC) + 2 bwd x (CSR + CSC) aggregations
         edges_per_epoch = 4 * E_in + 2 * E_out               # (gatmh: softmax passes re-walk the edges; same count used)
     value = edges_per_epoch / (ms_per_step * 1e-3)
@@ -221,7 +231,7 @@ def main():
     traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate:
+        if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate and args.workload == "reddit":
             traffic = pm["spmm_variant_1"]["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -233,10 +243,10 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on this box's cores ----------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate and args.workload == "reddit":
         cpu = cpu_baseline(ctx, g, args.cpu_rows)
 
-    if gat:   # the roofline / traffic bookkeeping above is for the GCN epoch's three launches
+    if gat or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
     if rank == 0:
         out = {
@@ -247,7 +257,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("Reddit GAT 2-layer 8-head, per-edge attention softmax (extension) full-graph" if args.gnn == "gatmh" else
                                     "Reddit GAT 2-layer (reference single-head prototype) full-graph" if gat else
-                                    "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph"),
+                                    "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph"
+                                    if args.workload == "reddit" else
+                                    f"{args.workload} GCN {len(DIMS) - 1}-layer ({V} verts, feat {'-'.join(map(str, DIMS))}) scale test"),
                        "graph": args.graph, "vertices": V, "edges": E_in,
                        "partitioning": f"contiguous x{world}" + (f" (emulating rank {args.emulate}, no exchange)" if args.emulate else ""),
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},

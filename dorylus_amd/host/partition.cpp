@@ -12,9 +12,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dorylus_host.h"
@@ -67,6 +69,24 @@ int dory_partition_build(const uint32_t *src, const uint32_t *dst, uint64_t nrec
     }
     const uint32_t N = g.N = (uint32_t)g.l2g.size();
 
+    // The three passes over the edge records are parallel over *vertex ownership*: thread t
+    // owns the global ids [t*V/T, (t+1)*V/T), scans all records in file order and applies only
+    // the updates that belong to vertices it owns -- no atomics, and the record order inside
+    // every column/row (the reference's edge-file order) is preserved by construction.
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if ((uint64_t)nrec < (1u << 20)) T = 1;                       // not worth the threads
+    if (const char *e = getenv("DORY_BUILD_THREADS")) T = (unsigned)atoi(e);   // explicit choice wins
+    if (T == 0) T = 1;
+    if (T > 256) T = 256;
+    auto owner_lo = [&](unsigned t) { return (uint32_t)((uint64_t)V * t / T); };
+    auto run_parallel = [&](const std::function<void(unsigned, uint32_t, uint32_t)> &fn) {
+        if (T == 1) { fn(0, 0, V); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t, owner_lo(t), owner_lo(t + 1));
+        for (auto &x : th) x.join();
+    };
+
     // pass 1: degrees, ghost membership, per-peer destination tables
     std::vector<uint64_t> inCnt(N, 0), outCnt(N, 0);
     std::vector<uint32_t> indegFile(V, 0);             // findGhostDegrees: file records only
@@ -77,44 +97,59 @@ int dory_partition_build(const uint32_t *src, const uint32_t *dst, uint64_t nrec
             fwdTab[p].assign(N, 0);
             bwdTab[p].assign(N, 0);
         }
-    auto count_edge = [&](uint32_t from, uint32_t to) {  // processEdge (dataloader.cpp:94-146)
-        const uint32_t pf = (uint32_t)parts[from], pt = (uint32_t)parts[to];
-        if (pf == me) {
-            const uint32_t lf = g2l[from];
-            ++outCnt[lf];
-            ++g.nout;
-            if (pt != me) {
-                isOutGhost[to] = 1;
-                fwdTab[pt][lf] = 1;
+    std::vector<uint64_t> tin(T, 0), tout(T, 0), tglob(T, 0);
+    run_parallel([&](unsigned t, uint32_t lo, uint32_t hi) {
+        uint64_t nin = 0, nout = 0, nglob = 0;
+        auto own = [&](uint32_t v) { return v >= lo && v < hi; };
+        auto count_edge = [&](uint32_t from, uint32_t to) {  // processEdge (dataloader.cpp:94-146)
+            const bool of = own(from), ot = own(to);
+            if (!of && !ot) return;                // ownership first: no table lookups for foreign records
+            const uint32_t pf = (uint32_t)parts[from], pt = (uint32_t)parts[to];
+            if (of) {                              // updates keyed by the source vertex
+                if (pf == me) {
+                    const uint32_t lf = g2l[from];
+                    ++outCnt[lf];
+                    ++nout;
+                    if (pt != me) fwdTab[pt][lf] = 1;
+                }
+                if (pt == me && pf != me) isInGhost[from] = 1;
             }
-        }
-        if (pt == me) {
-            const uint32_t lt = g2l[to];
-            ++inCnt[lt];
-            ++g.nin;
-            if (pf != me) {
-                isInGhost[from] = 1;
-                bwdTab[pf][lt] = 1;
+            if (ot) {                              // updates keyed by the destination vertex
+                if (pt == me) {
+                    const uint32_t lt = g2l[to];
+                    ++inCnt[lt];
+                    ++nin;
+                    if (pf != me) bwdTab[pf][lt] = 1;
+                }
+                if (pf == me && pt != me) isOutGhost[to] = 1;
             }
+        };
+        for (uint64_t i = 0; i < nrec; ++i) {
+            const uint32_t s = src[i], d = dst[i];
+            if (s == d) continue;                            // dataloader.cpp:268-269
+            count_edge(s, d);
+            if (undirected) count_edge(d, s);
+            if (t == 0) ++nglob;
+            if (own(d)) ++indegFile[d];                      // dataloader.cpp:204-214 (dst occurrences)
         }
-    };
-    for (uint64_t i = 0; i < nrec; ++i) {
-        const uint32_t s = src[i], d = dst[i];
-        if (s == d) continue;                            // dataloader.cpp:268-269
-        count_edge(s, d);
-        if (undirected) count_edge(d, s);
-        ++g.nglobal;
-        ++indegFile[d];                                  // dataloader.cpp:204-214 (dst occurrences)
-    }
+        tin[t] = nin; tout[t] = nout; tglob[t] = nglob;
+    });
+    for (unsigned t = 0; t < T; ++t) { g.nin += tin[t]; g.nout += tout[t]; g.nglobal += tglob[t]; }
 
     // ghost ranks in ascending global id (std::map order, dataloader.cpp:311-322)
-    std::vector<uint32_t> ghostRank(V, NONE);            // reused for in- then out-ghosts
-    for (uint32_t v = 0; v < V; ++v)
+    std::vector<uint32_t> ghostRankIn(V, NONE), ghostRankOut(V, NONE);
+    for (uint32_t v = 0; v < V; ++v) {
         if (isInGhost[v]) {
-            ghostRank[v] = (uint32_t)g.srcGhost.size();
+            ghostRankIn[v] = (uint32_t)g.srcGhost.size();
             g.srcGhost.push_back(v);
         }
+        if (isOutGhost[v]) {
+            ghostRankOut[v] = (uint32_t)g.dstGhost.size();
+            g.dstGhost.push_back(v);
+        }
+    }
     g.Gsrc = (uint32_t)g.srcGhost.size();
+    g.Gdst = (uint32_t)g.dstGhost.size();
 
     // send lists (dataloader.cpp:277-297)
     g.fwdCnt.assign(P, 0);
@@ -152,63 +187,50 @@ int dory_partition_build(const uint32_t *src, const uint32_t *dst, uint64_t nrec
     g.colIdx.resize(g.nout);
     g.csrVal.resize(g.nout);
 
-    // pass 2a: CSC (in-edges), record order inside each column (graph.hpp:167-190)
+    // pass 2: CSC (in-edges, owner = destination) and CSR (out-edges, owner = source), record
+    // order inside each column / row (graph.hpp:167-215)
     {
-        std::vector<uint64_t> cur(g.colPtr.begin(), g.colPtr.end() - 1);
-        auto fill_in = [&](uint32_t from, uint32_t to) {
-            if ((uint32_t)parts[to] != me) return;
-            const uint32_t lt = g2l[to];
-            const uint64_t pos = cur[lt]++;
-            float srcNorm;
-            if ((uint32_t)parts[from] == me) {
-                const uint32_t lf = g2l[from];
-                g.rowIdx[pos] = lf;
-                srcNorm = vnorm[lf];
-            } else {
-                g.rowIdx[pos] = N + ghostRank[from];
-                srcNorm = inv_sqrt_deg((uint64_t)indegFile[from] + 1);
+        std::vector<uint64_t> curIn(g.colPtr.begin(), g.colPtr.end() - 1), curOut(g.rowPtr.begin(), g.rowPtr.end() - 1);
+        run_parallel([&](unsigned, uint32_t lo, uint32_t hi) {
+            auto own = [&](uint32_t v) { return v >= lo && v < hi; };
+            auto fill = [&](uint32_t from, uint32_t to) {
+                const bool of = own(from), ot = own(to);
+                if (!of && !ot) return;
+                const bool fl = (uint32_t)parts[from] == me, tl = (uint32_t)parts[to] == me;
+                if (tl && ot) {                      // in-edge of local vertex `to`
+                    const uint32_t lt = g2l[to];
+                    const uint64_t pos = curIn[lt]++;
+                    float srcNorm;
+                    if (fl) {
+                        g.rowIdx[pos] = g2l[from];
+                        srcNorm = vnorm[g2l[from]];
+                    } else {
+                        g.rowIdx[pos] = N + ghostRankIn[from];
+                        srcNorm = inv_sqrt_deg((uint64_t)indegFile[from] + 1);
+                    }
+                    g.cscVal[pos] = srcNorm * vnorm[lt];         // e.setData(srcNorm * vtxNorm)
+                }
+                if (fl && of) {                      // out-edge of local vertex `from`
+                    const uint32_t lf = g2l[from];
+                    const uint64_t pos = curOut[lf]++;
+                    float dstNorm;
+                    if (tl) {
+                        g.colIdx[pos] = g2l[to];
+                        dstNorm = vnorm[g2l[to]];
+                    } else {
+                        g.colIdx[pos] = N + ghostRankOut[to];
+                        dstNorm = inv_sqrt_deg((uint64_t)indegFile[to] + 1);
+                    }
+                    g.csrVal[pos] = vnorm[lf] * dstNorm;         // e.setData(vtxNorm * dstNorm)
+                }
+            };
+            for (uint64_t i = 0; i < nrec; ++i) {
+                const uint32_t s = src[i], d = dst[i];
+                if (s == d) continue;
+                fill(s, d);
+                if (undirected) fill(d, s);
             }
-            g.cscVal[pos] = srcNorm * vnorm[lt];         // e.setData(srcNorm * vtxNorm)
-        };
-        for (uint64_t i = 0; i < nrec; ++i) {
-            const uint32_t s = src[i], d = dst[i];
-            if (s == d) continue;
-            fill_in(s, d);
-            if (undirected) fill_in(d, s);
-        }
-    }
-    // out-ghost ranks
-    for (uint32_t v : g.srcGhost) ghostRank[v] = NONE;
-    for (uint32_t v = 0; v < V; ++v)
-        if (isOutGhost[v]) {
-            ghostRank[v] = (uint32_t)g.dstGhost.size();
-            g.dstGhost.push_back(v);
-        }
-    g.Gdst = (uint32_t)g.dstGhost.size();
-    // pass 2b: CSR (out-edges) (graph.hpp:192-215)
-    {
-        std::vector<uint64_t> cur(g.rowPtr.begin(), g.rowPtr.end() - 1);
-        auto fill_out = [&](uint32_t from, uint32_t to) {
-            if ((uint32_t)parts[from] != me) return;
-            const uint32_t lf = g2l[from];
-            const uint64_t pos = cur[lf]++;
-            float dstNorm;
-            if ((uint32_t)parts[to] == me) {
-                const uint32_t lt = g2l[to];
-                g.colIdx[pos] = lt;
-                dstNorm = vnorm[lt];
-            } else {
-                g.colIdx[pos] = N + ghostRank[to];
-                dstNorm = inv_sqrt_deg((uint64_t)indegFile[to] + 1);
-            }
-            g.csrVal[pos] = vnorm[lf] * dstNorm;         // e.setData(vtxNorm * dstNorm)
-        };
-        for (uint64_t i = 0; i < nrec; ++i) {
-            const uint32_t s = src[i], d = dst[i];
-            if (s == d) continue;
-            fill_out(s, d);
-            if (undirected) fill_out(d, s);
-        }
+        });
     }
     *out = pp.release();
     return DORY_OK;

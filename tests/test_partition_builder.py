@@ -72,3 +72,20 @@ def test_builder_rejects_bad_input(da):
         da.Partition.build([0], [1], [0, 3], 0, 2)                # partition id 3 >= P
     with pytest.raises(da.DoryError):
         da.Partition.load("/nonexistent/graph.0.bin")
+
+
+@pytest.mark.parametrize("threads", [2, 5, 16])
+def test_builder_parallel_passes_are_order_preserving(da, threads, monkeypatch):
+    """the vertex-ownership parallel passes give the same bytes as the sequential build / the oracle"""
+    monkeypatch.setenv("DORY_BUILD_THREADS", str(threads))
+    rng = np.random.default_rng(threads)
+    V, E, P = 333, 9000, 3
+    src, dst = rng.integers(0, V, E), rng.integers(0, V, E)
+    src[:500] = 7                                   # hub with many duplicate edges: order matters
+    parts = rng.integers(0, P, V)
+    for und in (False, True):
+        for nid in range(P):
+            part = da.Partition.build(src, dst, parts, nid, P, und)
+            with tempfile.NamedTemporaryFile() as f:
+                part.save(f.name)
+                assert open(f.name, "rb").read() == po.dump_bytes(po.preprocess(src, dst, parts, nid, P, und))
