@@ -248,10 +248,13 @@ def main():
 
     if gat or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
+    scale_name = {"reddit": "Reddit-scale"}.get(args.workload, args.workload + "-scale")
     if rank == 0:
         out = {
-            "metric": ("full-graph GAT (reference prototype) epoch: aggregated edges/sec, Reddit-scale synthetic" if gat else
-                       "full-graph GCN epoch: aggregated edges/sec (epoch time in ms_per_step), Reddit-scale synthetic, 2-layer 602-128-41"),
+            "metric": (f"full-graph GAT ({'8-head extension' if args.gnn == 'gatmh' else 'reference prototype'}) epoch: "
+                       f"aggregated edges/sec, {scale_name} synthetic" if gat else
+                       f"full-graph GCN epoch: aggregated edges/sec (epoch time in ms_per_step), {scale_name} synthetic, "
+                       f"{len(DIMS) - 1}-layer {'-'.join(map(str, DIMS))}"),
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -772,7 +772,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 HIPCK(c, launch_gatmh_elu_bwd(c->N, o->cols, dh->d, dh->ld, o->d, o->ld, dO->d, dO->ld, c->compute));
             }
         }
-        int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float));
+        int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
         Timed t(c, "spmm", c->compute);
         HIPCK(c, launch_gatmh_backward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->rowPtr, c->colIdx, z->d, el->d,

@@ -272,6 +272,150 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_kernel(GatMhArgs a, co
     }
 }
 
+// ---- backward, (edge, head)-per-lane layout (K > 1, D in {8,16,32}) -----------------------
+// lane = j*KP + k owns head k of the chunk's j-th edge and keeps that head's D-float slices
+// in registers, so the per-edge dot product <dO[v,k,:], Z[u,k,:]> needs no cross-lane
+// reduction (the feature-per-lane kernels above pay log2(D) shuffles per edge and chunk);
+// the KP lanes of an edge read one contiguous K*D row.  Sums over edges are combined across
+// the j lanes once per vertex.
+template <int DL, int SP>
+__global__ __launch_bounds__(256) void gatmh_backward_dst_eh_kernel(GatMhArgs a, const float *z, const float *el,
+                                                                    const float *er, const float *m_in,
+                                                                    const float *den_in, const float *d_o,
+                                                                    float *t_out, float *der_out, float4 *st4) {
+    // lane = (j*KP + k)*SP + s: edge j of the chunk, head k, s-th DL-float piece of the head's D features
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= a.N) return;
+    uint32_t KP = 1;
+    while (KP < a.K) KP <<= 1;
+    const uint32_t LPE = KP * SP, EPC = 64 / LPE;
+    const uint32_t sp = lane % SP, k = (lane / SP) % KP, j = lane / LPE;
+    const bool kok = k < a.K;
+    const uint32_t kk = kok ? k : 0;
+    const uint32_t foff = kk * a.D + sp * DL;          // first feature of this lane's piece
+    const uint32_t nval = sp * DL < a.D ? min((uint32_t)DL, a.D - sp * DL) : 0u;   // K = 1: D need not fill the pieces
+    float dov[DL];
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(d_o + (size_t)v * a.ld + foff);
+#pragma unroll
+        for (int q = 0; q < DL / 4; ++q) {
+            const float4 x = p[q];
+            dov[4 * q] = x.x; dov[4 * q + 1] = x.y; dov[4 * q + 2] = x.z; dov[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int d = 0; d < DL; ++d) dov[d] = (uint32_t)d < nval ? dov[d] : 0.f;   // padding columns never count
+    }
+    const float er_v = er[(size_t)v * a.ldk + kk], m_v = m_in[(size_t)v * a.ldk + kk];
+    const float idn = 1.f / den_in[(size_t)v * a.ldk + kk];
+    float t = 0.f, a1 = 0.f, a2 = 0.f;
+    const uint64_t e_beg = a.ptr[v], e_end = a.ptr[v + 1];
+    for (uint64_t e0 = e_beg; e0 <= e_end; e0 += EPC) {
+        const uint64_t e = e0 + j;
+        const bool live = e <= e_end && kok;
+        const uint32_t u = (e < e_end) ? a.idx[e] : v;
+        const float4 *zp = reinterpret_cast<const float4 *>(z + (size_t)u * a.ld + foff);
+        float da = 0.f;
+#pragma unroll
+        for (int q = 0; q < DL / 4; ++q) {
+            const float4 x = zp[q];
+            da = fmaf(dov[4 * q], x.x, da); da = fmaf(dov[4 * q + 1], x.y, da);
+            da = fmaf(dov[4 * q + 2], x.z, da); da = fmaf(dov[4 * q + 3], x.w, da);
+        }
+#pragma unroll
+        for (int o = 1; o < SP; o <<= 1) da += __shfl_xor(da, o, 64);
+        const float pre = el[(size_t)u * a.ldk + kk] + er_v;
+        const float al = live ? __expf(lrelu02(pre) - m_v) * idn : 0.f;
+        const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
+        t = fmaf(al, da, t);
+        a1 = fmaf(al * da, lp, a1);
+        a2 = fmaf(al, lp, a2);
+    }
+    for (uint32_t off = LPE; off < 64; off <<= 1) {
+        t += __shfl_xor(t, off, 64);
+        a1 += __shfl_xor(a1, off, 64);
+        a2 += __shfl_xor(a2, off, 64);
+    }
+    if (j == 0 && sp == 0 && kok) {
+        t_out[(size_t)v * a.ldk + k] = t;
+        der_out[(size_t)v * a.ldk + k] = a1 - t * a2;
+        st4[(size_t)v * a.K + k] = make_float4(er_v, m_v, idn, t);   // what the source side needs of (v,k): one 16-B gather
+    }
+}
+
+template <int DL, int SP>
+__global__ __launch_bounds__(256) void gatmh_backward_src_eh_kernel(GatMhArgs a, const float *z, const float *el,
+                                                                    const float4 *st4, const float *der_in,
+                                                                    const float *d_o, const float *a_l,
+                                                                    const float *a_r, float *del_out, float *dz) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= a.N) return;
+    uint32_t KP = 1;
+    while (KP < a.K) KP <<= 1;
+    const uint32_t LPE = KP * SP, EPC = 64 / LPE;
+    const uint32_t sp = lane % SP, k = (lane / SP) % KP, j = lane / LPE;
+    const bool kok = k < a.K;
+    const uint32_t kk = kok ? k : 0;
+    const uint32_t foff = kk * a.D + sp * DL;
+    const uint32_t nval = sp * DL < a.D ? min((uint32_t)DL, a.D - sp * DL) : 0u;
+    float zu[DL], acc[DL];
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(z + (size_t)u * a.ld + foff);
+#pragma unroll
+        for (int q = 0; q < DL / 4; ++q) {
+            const float4 x = p[q];
+            zu[4 * q] = x.x; zu[4 * q + 1] = x.y; zu[4 * q + 2] = x.z; zu[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int d = 0; d < DL; ++d) {
+            zu[d] = (uint32_t)d < nval ? zu[d] : 0.f;
+            acc[d] = 0.f;
+        }
+    }
+    const float el_u = el[(size_t)u * a.ldk + kk];
+    float del = 0.f;
+    const uint64_t e_beg = a.ptr[u], e_end = a.ptr[u + 1];
+    for (uint64_t e0 = e_beg; e0 <= e_end; e0 += EPC) {
+        const uint64_t e = e0 + j;
+        const bool live = e <= e_end && kok;
+        const uint32_t v = (e < e_end) ? a.idx[e] : u;
+        const float4 sv = st4[(size_t)v * a.K + kk];   // er, m, 1/den, t of (v,k)
+        const float4 *dp = reinterpret_cast<const float4 *>(d_o + (size_t)v * a.ld + foff);
+        float dv[DL];
+        float da = 0.f;
+#pragma unroll
+        for (int q = 0; q < DL / 4; ++q) {
+            const float4 x = dp[q];
+            dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int d = 0; d < DL; ++d) da = fmaf(dv[d], zu[d], da);
+#pragma unroll
+        for (int o = 1; o < SP; o <<= 1) da += __shfl_xor(da, o, 64);
+        const float pre = el_u + sv.x;
+        const float al = live ? __expf(lrelu02(pre) - sv.y) * sv.z : 0.f;
+        const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
+        del = fmaf(al * (da - sv.w), lp, del);
+#pragma unroll
+        for (int d = 0; d < DL; ++d) acc[d] = fmaf(al, dv[d], acc[d]);
+    }
+    for (uint32_t off = LPE; off < 64; off <<= 1) {
+        del += __shfl_xor(del, off, 64);
+#pragma unroll
+        for (int d = 0; d < DL; ++d) acc[d] += __shfl_xor(acc[d], off, 64);
+    }
+    if (j == 0 && kok) {
+        const float dr = der_in[(size_t)u * a.ldk + k];
+        float *out = dz + (size_t)u * a.ld + foff;
+        const float *al_p = a_l + foff, *ar_p = a_r + foff;
+#pragma unroll
+        for (int d = 0; d < DL; ++d)
+            if ((uint32_t)d < nval) out[d] = acc[d] + del * al_p[d] + dr * ar_p[d];
+        if (sp == 0) del_out[(size_t)u * a.ldk + k] = del;
+    }
+}
+
 // da[f] = sum_u w[u, f/D] * Z[u,f]   (two stages, deterministic)
 __global__ __launch_bounds__(256) void gatmh_dattn_partial_kernel(uint32_t N, uint32_t KD, uint32_t D,
                                                                   const float *z, uint32_t ld, const float *w,
@@ -381,10 +525,29 @@ hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld
         hipLaunchKernelGGL(gatmh_backward_src_kernel<NC>, gr, bl, 0, s, ar, z, el, er, m, den, t, der, d_o, a_l, a_r,   \
                            del, dz);                                                                                   \
     } while (0)
-    if (KD <= 64) GATMH_BWD(1);
+    // (edge, head[, piece])-per-lane kernels; st4 = (er, m, 1/den, t) per (v,k), carved from the scratch buffer
+    float4 *st4 = reinterpret_cast<float4 *>(scratch);
+    const size_t st4_bytes = ((size_t)N * K * sizeof(float4) + 255) & ~(size_t)255;
+    const bool eh_fits = scratch_bytes >= st4_bytes + (size_t)KD * sizeof(float);
+#define GATMH_BWD_EH(DL, SP)                                                                                            \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((gatmh_backward_dst_eh_kernel<DL, SP>), gr, bl, 0, s, ac, z, el, er, m, den, d_o, t, der,    \
+                           st4);                                                                                       \
+        hipLaunchKernelGGL((gatmh_backward_src_eh_kernel<DL, SP>), gr, bl, 0, s, ar, z, el, st4, der, d_o, a_l, a_r,    \
+                           del, dz);                                                                                   \
+        scratch += st4_bytes / sizeof(float);                                                                          \
+        scratch_bytes -= st4_bytes;                                                                                    \
+    } while (0)
+    if (eh_fits && K > 1 && D == 8) GATMH_BWD_EH(8, 1);
+    else if (eh_fits && K > 1 && D == 16) GATMH_BWD_EH(16, 1);
+    else if (eh_fits && K > 1 && D == 32) GATMH_BWD_EH(32, 1);
+    else if (eh_fits && K == 1 && D <= 64 && ld >= 64) GATMH_BWD_EH(16, 4);   // one head split over 4 lanes (D = 41 -> 64)
+    else if (eh_fits && K == 1 && D <= 128 && ld >= 128) GATMH_BWD_EH(32, 4);
+    else if (KD <= 64) GATMH_BWD(1);
     else if (KD <= 128) GATMH_BWD(2);
     else GATMH_BWD(4);
 #undef GATMH_BWD
+#undef GATMH_BWD_EH
     uint32_t nb = 1024;
     while (nb > 1 && (size_t)nb * KD * sizeof(float) > scratch_bytes) nb >>= 1;
     uint32_t rpb = (N + nb - 1) / nb;

@@ -12,6 +12,8 @@ RTOL = 1e-4
     ([24, 32, 8], [4, 2], 200, 1500),        # 4 heads x 8, two output heads (of 8 classes) averaged
     ([40, 128, 41], [8, 1], 300, 4000),      # the Reddit layer shape: 8 heads x 16 -> 41 classes
     ([16, 64, 7], [1, 1], 150, 900),         # single head: reductions span the whole row
+    ([20, 128, 5], [4, 1], 180, 1300),       # 4 heads x 32
+    ([12, 100, 6], [1, 1], 160, 1100),       # one head of 100 features: split over 4 lanes, last piece ragged
 ])
 def test_gat_mh_epoch_vs_oracle(dims, heads, V, E):
     import dorylus_amd as da

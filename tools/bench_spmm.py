@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--nbs", type=int, nargs="+", default=[0])
     ap.add_argument("--forms", type=int, nargs="+", default=[1])
     ap.add_argument("--window", type=int, default=0, help="draw sources from [0, window): L2-resident gather probe")
+    ap.add_argument("--opt", nargs="*", default=[], help="extra context options key=value (e.g. spmm_march_nacc=4)")
     a = ap.parse_args()
     N = 232965
     E = int(114615892 * a.scale)
@@ -67,6 +68,9 @@ def main():
         ctx.graph_upload(g)
         ctx.preallocate()
         ctx.fill_uniform(0, "x", 1)
+        for kv in a.opt:
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
         _, _, ld, _ = ctx.info(0, "x")
         comp = E * 8 + 8 * (N + 1) + 4 * N + 4 * F * N + 4 * F * N
         for variant in a.variants:
