@@ -21,7 +21,8 @@ SYMBOLS = [
     "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
     "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
-    "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_ctx_describe",
+    "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
+    "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
     "dory_gatmh_heads",
 ]
 
@@ -75,6 +76,9 @@ def load():
         "dory_timing_get": [vp, cp, C.POINTER(C.c_double), C.POINTER(u64)],
         "dory_timing_reset": [vp],
         "dory_set_option": [vp, cp, C.c_int64],
+        "dory_get_option": [vp, cp, C.POINTER(C.c_int64)],
+        "dory_epoch_graph_begin": [vp], "dory_epoch_graph_end": [vp], "dory_epoch_graph_launch": [vp, u32],
+        "dory_epoch_graph_drop": [vp],
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
         "dory_gatmh_heads": [vp, vp],
         # include/dorylus_host.h
@@ -304,3 +308,21 @@ class Context:
 
     def set_option(self, key, value):
         self._ck(self.lib.dory_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._ck(self.lib.dory_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    # epoch graph (hipGraph replay of one recorded epoch; single partition)
+    def epoch_graph_begin(self):
+        self._ck(self.lib.dory_epoch_graph_begin(self.h))
+
+    def epoch_graph_end(self):
+        self._ck(self.lib.dory_epoch_graph_end(self.h))
+
+    def epoch_graph_launch(self, epochs=1):
+        self._ck(self.lib.dory_epoch_graph_launch(self.h, int(epochs)))
+
+    def epoch_graph_drop(self):
+        self._ck(self.lib.dory_epoch_graph_drop(self.h))

@@ -55,7 +55,7 @@ struct Timed {
     const char *fam;
     hipEvent_t a = nullptr, b = nullptr;
     Timed(dory_ctx *ctx, const char *family, hipStream_t st) : c(ctx), s(st), fam(family) {
-        if (!c->timing) return;
+        if (!c->timing || c->capturing) return;
         if (c->ev_pool.empty()) {
             hipEventCreate(&a);
             hipEventCreate(&b);
@@ -67,7 +67,7 @@ struct Timed {
         hipEventRecord(a, s);
     }
     ~Timed() {
-        if (!c->timing) return;
+        if (!c->timing || c->capturing) return;
         hipEventRecord(b, s);
         c->pending.push_back({fam, a, b});
     }
@@ -127,6 +127,7 @@ int upload_array(dory_ctx *c, T **dst, const T *src, uint64_t n) {
 
 int ensure_scratch(dory_ctx *c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return DORY_OK;
+    if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: scratch would have to grow while recording (run one eager epoch first)");
     if (c->scratch) {
         HIPCK(c, hipStreamSynchronize(c->compute));
         hipFree(c->scratch);
@@ -155,7 +156,7 @@ int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const 
     g.A = A.d; g.lda = A.ld; g.B = B.d; g.ldb = B.ld; g.C = C.d; g.ldc = C.ld;
     g.epilogue = C2 ? EPI_TANH : EPI_NONE;
     if (C2) { g.C2 = C2->d; g.ldc2 = C2->ld; }
-    size_t need = gemm_scratch_bytes(M, N);
+    size_t need = gemm_scratch_bytes(M, N, K);
     if (need > ((size_t)256 << 20)) need = (size_t)256 << 20;
     int rc = ensure_scratch(c, need);
     if (rc) return rc;
@@ -211,6 +212,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
     return DORY_OK;
@@ -250,6 +252,10 @@ int dory_destroy(dory_ctx *c) {
     }
     if (c->scratch) hipFree(c->scratch);
     if (c->partial) hipFree(c->partial);
+    if (c->epoch_exec) hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) hipGraphDestroy(c->epoch_graph);
+    if (c->d_lr_table) hipFree(c->d_lr_table);
+    if (c->d_replay_idx) hipFree(c->d_replay_idx);
     if (c->send_buf) hipFree(c->send_buf);
     if (c->recv_buf) hipFree(c->recv_buf);
     if (c->d_stat) hipFree(c->d_stat);
@@ -624,6 +630,8 @@ static int ensure_blocked(dory_ctx *c, bool csc, int group) {
     bool &built = csc ? c->blkIn_built : c->blkOut_built;
     const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
     // the block structure serves every slab width; only an explicit block count forces a rebuild
+    if (c->capturing && (!built || (want_nb && B.nb != (want_nb + 7) / 8 * 8)) && !(csc ? c->blkIn_na : c->blkOut_na))
+        return fail(c, DORY_ERR_ARG, "epoch graph: blocked adjacency would have to be (re)built while recording");
     if (built && want_nb && B.nb != (want_nb + 7) / 8 * 8) {
         HIPCK(c, hipStreamSynchronize(c->compute));
         free_blocked(&B);
@@ -635,7 +643,10 @@ static int ensure_blocked(dory_ctx *c, bool csc, int group) {
         // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
         // hundred L2 windows at most.  Larger partitions keep K1.
         const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u);
-        if (nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
+        // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
+        // K1 then gathers from L2 without partial sums or a second kernel
+        const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20);
+        if (tiny || nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
             (csc ? c->blkIn_na : c->blkOut_na) = true;
             return DORY_OK;
         }
@@ -681,6 +692,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         const size_t need = blocked_partial_bytes(a, B);
         if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
             if (need > c->partial_bytes) {
+                if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: partial buffer would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));
                 if (c->partial) hipFree(c->partial);
                 c->partial = nullptr;
@@ -1132,6 +1144,7 @@ int dory_adam_config(dory_ctx *c, float learning_rate) {
     CHECK_CTX(c);
     c->adam.lr = learning_rate;
     c->adam.epochs = 1;
+    c->lr_table_left = 0;   // an epoch graph's step-size table is refilled on its next launch
     return DORY_OK;
 }
 
@@ -1159,9 +1172,16 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
             NCCLCK(c, ncclAllReduce(g.d, g.d, n, ncclFloat, ncclSum, (ncclComm_t)c->nccl, c->compute));
         }
         Timed t(c, "adam", c->compute);
-        HIPCK(c, launch_adam(w.d, g.d, c->adam_m[layer][name].d, c->adam_v[layer][name].d, n, lr_t, c->compute));
+        if (c->capturing)   // replayed epochs: step size from the table dory_epoch_graph_launch fills
+            HIPCK(c, launch_adam_table(w.d, g.d, c->adam_m[layer][name].d, c->adam_v[layer][name].d, n, c->d_lr_table,
+                                       c->d_replay_idx, c->compute));
+        else
+            HIPCK(c, launch_adam(w.d, g.d, c->adam_m[layer][name].d, c->adam_v[layer][name].d, n, lr_t, c->compute));
     }
-    if (layer == 0) c->adam.epochs += 1;  // "if(layer == 0) nextIteration();" (AdamOptimizer.cpp:49-50)
+    if (layer == 0 && !c->capturing) {   // "if(layer == 0) nextIteration();" (AdamOptimizer.cpp:49-50)
+        c->adam.epochs += 1;
+        c->lr_table_left = 0;            // eager step: a recorded epoch's table no longer lines up
+    }
     return DORY_OK;
 }
 
@@ -1199,6 +1219,105 @@ int dory_timing_reset(dory_ctx *c) {
     c->times.clear();
     return DORY_OK;
 }
+// ---------------------------------------------------------------------------------------
+// Epoch graph: one epoch of C-ABI calls recorded into a hipGraph and replayed, so that a
+// launch-bound epoch (Cora-sized graphs: ~35 kernels of a few microseconds) costs one
+// graph launch.  No reference counterpart; single partition only (the exchange is not
+// recorded).  Everything an epoch allocates lazily must exist already: run one eager epoch
+// first.  Per-epoch host scalars do not survive recording, so Adam's step size comes from a
+// device table indexed by a replay counter that the graph's last node bumps.
+static float adam_lr_t(const dory_ctx *c, unsigned epochs) {   // AdamOptimizer::nextIteration, as dory_weight_update
+    const float b1p = (float)std::pow((double)0.9f, (double)epochs);
+    const float b2p = (float)std::pow((double)0.999f, (double)epochs);
+    return (float)(c->adam.lr * (std::sqrt((double)(1 - b2p))) / (1 - b1p));
+}
+
+static void epoch_graph_drop_locked(dory_ctx *c) {
+    if (c->capturing) {   // abandon a recording in progress
+        hipGraph_t g = nullptr;
+        hipStreamEndCapture(c->compute, &g);
+        if (g) hipGraphDestroy(g);
+        c->capturing = false;
+    }
+    if (c->epoch_exec) hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) hipGraphDestroy(c->epoch_graph);
+    c->epoch_exec = nullptr;
+    c->epoch_graph = nullptr;
+    c->lr_table_left = 0;
+}
+
+int dory_epoch_graph_drop(dory_ctx *c) {
+    CHECK_CTX(c);
+    epoch_graph_drop_locked(c);
+    return DORY_OK;
+}
+
+int dory_epoch_graph_begin(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "epoch_graph_begin: preallocate first");
+    if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "epoch graph: single partition only (the halo exchange is not recorded)");
+    if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch_graph_begin: already recording");
+    epoch_graph_drop_locked(c);
+    if (!c->d_replay_idx) HIPCK(c, hipMalloc((void **)&c->d_replay_idx, 256));
+    if (!c->d_lr_table) {
+        c->lr_table_cap = 1024;
+        HIPCK(c, hipMalloc((void **)&c->d_lr_table, c->lr_table_cap * sizeof(float)));
+    }
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    HIPCK(c, hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return DORY_OK;
+}
+
+int dory_epoch_graph_end(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->capturing) return fail(c, DORY_ERR_ARG, "epoch_graph_end: not recording");
+    hipError_t e = launch_bump_counter(c->d_replay_idx, c->compute);
+    hipGraph_t g = nullptr;
+    hipError_t e2 = hipStreamEndCapture(c->compute, &g);
+    c->capturing = false;
+    if (e != hipSuccess || e2 != hipSuccess || !g) {
+        if (g) hipGraphDestroy(g);
+        return fail(c, DORY_ERR_HIP, "epoch_graph_end: recording failed (%s)", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    c->epoch_graph = g;
+    e = hipGraphInstantiate(&c->epoch_exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        c->epoch_exec = nullptr;
+        epoch_graph_drop_locked(c);
+        return fail(c, DORY_ERR_HIP, "epoch_graph_end: hipGraphInstantiate failed (%s)", hipGetErrorString(e));
+    }
+    return DORY_OK;
+}
+
+int dory_epoch_graph_launch(dory_ctx *c, uint32_t epochs) {
+    CHECK_CTX(c);
+    if (!c->epoch_exec) return fail(c, DORY_ERR_ARG, "epoch_graph_launch: no recorded epoch");
+    for (uint32_t i = 0; i < epochs; ++i) {
+        if (c->lr_table_left == 0) {
+            // step sizes of the next replays, a pure function of the iteration count: filled well
+            // ahead so that the host copy + counter reset happen once per lr_table_cap epochs
+            HIPCK(c, hipStreamSynchronize(c->compute));   // previous replays have read the old table
+            c->lr_table_host.resize(c->lr_table_cap);
+            for (uint32_t k = 0; k < c->lr_table_cap; ++k) c->lr_table_host[k] = adam_lr_t(c, c->adam.epochs + k);
+            HIPCK(c, hipMemcpy(c->d_lr_table, c->lr_table_host.data(), c->lr_table_cap * sizeof(float), hipMemcpyHostToDevice));
+            HIPCK(c, hipMemset(c->d_replay_idx, 0, sizeof(uint32_t)));
+            c->lr_table_left = c->lr_table_cap;
+        }
+        HIPCK(c, hipGraphLaunch(c->epoch_exec, c->compute));
+        c->lr_table_left -= 1;
+        c->adam.epochs += 1;
+    }
+    return DORY_OK;
+}
+
+int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
+    CHECK_CTX(c);
+    if (!key || !value || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
+    *value = c->opt[key];
+    return DORY_OK;
+}
+
 int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
     CHECK_CTX(c);
     if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");

@@ -115,6 +115,16 @@ struct dory_ctx {
     void *nccl = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
 
+    // epoch graph (hipGraph replay of one captured epoch; single partition)
+    bool capturing = false;
+    hipGraph_t epoch_graph = nullptr;
+    hipGraphExec_t epoch_exec = nullptr;
+    float *d_lr_table = nullptr;       // Adam step size of each replay of the current launch batch
+    uint32_t lr_table_cap = 0;
+    uint32_t lr_table_left = 0;        // prepared entries not yet consumed by a replay
+    uint32_t *d_replay_idx = nullptr;  // bumped by the last node of the graph
+    std::vector<float> lr_table_host;
+
     // options / timing
     std::map<std::string, int64_t> opt;
     bool timing = false;
@@ -173,7 +183,7 @@ struct GemmArgs {
     const float *Zp; uint32_t ldz;
 };
 hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s);
-size_t gemm_scratch_bytes(uint32_t M, uint32_t N);
+size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K);
 
 // K3/K4 elementwise + loss
 hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, uint32_t lda,
@@ -239,5 +249,8 @@ hipError_t launch_scatter_rows(float *dst, const float *src, uint32_t ld, uint32
 // K7 Adam
 hipError_t launch_adam(float *w, const float *g, float *m, float *v, uint64_t n, float lr_t,
                        hipStream_t s);
+hipError_t launch_adam_table(float *w, const float *g, float *m, float *v, uint64_t n, const float *lr_table,
+                             const uint32_t *idx, hipStream_t s);
+hipError_t launch_bump_counter(uint32_t *idx, hipStream_t s);
 
 }  // namespace dory

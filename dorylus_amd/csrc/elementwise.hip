@@ -344,7 +344,15 @@ __global__ void colsum_final_kernel(uint32_t F, const float *partial, uint32_t n
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F) return;
     float s = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) s += partial[(size_t)b * F + j];
+    uint32_t b = 0;
+    for (; b + 8 <= nb; b += 8) {   // eight loads in flight, adds in block order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * F + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; ++b) s += partial[(size_t)b * F + j];
     out[j] = s;
 }
 
@@ -360,7 +368,7 @@ hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, 
                            float *partial, size_t partial_bytes, float *out, hipStream_t s) {
     if (F == 0) return hipSuccess;
     uint32_t nb = 1024;
-    while (nb > 1 && (size_t)nb * F * sizeof(float) > partial_bytes) nb >>= 1;
+    while (nb > 1 && (nb > N / 64 || (size_t)nb * F * sizeof(float) > partial_bytes)) nb >>= 1;   // >= 64 rows per block
     const uint32_t rpb = (N + nb - 1) / nb > 0 ? (N + nb - 1) / nb : 1;
     nb = (N + rpb - 1) / rpb;
     if (nb == 0) nb = 1;
@@ -438,6 +446,38 @@ hipError_t launch_adam(float *w, const float *g, float *m, float *v, uint64_t n,
     if (n == 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t);
+    return hipGetLastError();
+}
+
+// the same update inside a replayed epoch graph: the step size of replay number *idx comes
+// from a table the host filled before the launches (kernel arguments are frozen at capture)
+__global__ void adam_table_kernel(float *w, const float *g, float *m, float *v, uint64_t n, const float *lr_table,
+                                  const uint32_t *idx) {
+    const float BETA1 = .9f, BETA2 = .999f, EPSILON = 1e-07f;
+    const float lr_t = lr_table[*idx];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const float gt = g[i];
+        const float pm = m[i], pd = v[i];
+        const float nm = (float)(BETA1 * pm + (1. - BETA1) * gt);
+        const float nv = (float)(BETA2 * pd + (1. - BETA2) * gt * gt);
+        m[i] = nm;
+        v[i] = nv;
+        const float delta = (float)(lr_t * nm / (sqrt((double)nv) + EPSILON));
+        w[i] -= delta;
+    }
+}
+__global__ void bump_counter_kernel(uint32_t *idx) { *idx += 1u; }
+
+hipError_t launch_adam_table(float *w, const float *g, float *m, float *v, uint64_t n, const float *lr_table,
+                             const uint32_t *idx, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_table_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_table, idx);
+    return hipGetLastError();
+}
+hipError_t launch_bump_counter(uint32_t *idx, hipStream_t s) {
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, idx);
     return hipGetLastError();
 }
 

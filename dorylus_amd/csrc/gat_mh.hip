@@ -433,7 +433,15 @@ __global__ void gatmh_colsum_final_kernel(uint32_t F, const float *partial, uint
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F) return;
     float s = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) s += partial[(size_t)b * F + j];
+    uint32_t b = 0;
+    for (; b + 8 <= nb; b += 8) {   // eight loads in flight, adds in block order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * F + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; ++b) s += partial[(size_t)b * F + j];
     out[j] = s;
 }
 
@@ -549,7 +557,7 @@ hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld
 #undef GATMH_BWD
 #undef GATMH_BWD_EH
     uint32_t nb = 1024;
-    while (nb > 1 && (size_t)nb * KD * sizeof(float) > scratch_bytes) nb >>= 1;
+    while (nb > 1 && (nb > N / 64 || (size_t)nb * KD * sizeof(float) > scratch_bytes)) nb >>= 1;   // >= 64 rows per block
     uint32_t rpb = (N + nb - 1) / nb;
     if (rpb == 0) rpb = 1;
     nb = (N + rpb - 1) / rpb;

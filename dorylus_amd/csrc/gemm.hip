@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, fl
 // second stage of split-K: C = sum_z partial[z] in z order (deterministic); eight
 // partials are requested at a time so the loads overlap, the adds stay sequential
 __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M, uint32_t N,
-                                     uint32_t ldc, uint32_t S) {
+                                     uint32_t ldc, uint32_t S, float *C2 /*EPI_TANH: tanh(C), or nullptr*/,
+                                     uint32_t ldc2) {
     const size_t n = (size_t)M * ldc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -214,12 +215,15 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
         }
         for (; z < S; ++z) s += partial[(size_t)z * n + i];
         C[i] = s;
+        if (C2) C2[(i / ldc) * ldc2 + (i % ldc)] = tanhf(s);
     }
 }
 
 static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
     const uint32_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
-    if (tiles >= 512 || K <= 4096) return 1;
+    // a workgroup walks its k-tiles one after the other (~1.9 us each): with few tiles even a
+    // Cora-sized K (2 708 rows -> 85 k-tiles = 160 us on one workgroup) wants to be split
+    if (tiles >= 512 || K < 8 * BK) return 1;
     uint32_t s = (512 + tiles - 1) / tiles;             // aim at ~512 workgroups = 256 CUs x 2 resident blocks
     const uint32_t maxs = (K + 4 * BK - 1) / (4 * BK);  // at least 4 k-tiles per split
     if (s > maxs) s = maxs;
@@ -227,10 +231,10 @@ static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
     return s < 1 ? 1 : s;
 }
 
-size_t gemm_scratch_bytes(uint32_t M, uint32_t N) {
-    // only split-K (small M x N, long K) uses scratch: 512 partials at most
-    const size_t mn = (size_t)M * pad_ld(N);
-    return mn <= (size_t)2048 * 2048 ? mn * 512 * sizeof(float) : 0;
+size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K) {
+    // only split-K (few output tiles, long K) uses scratch: one M x ld(N) partial per split
+    const uint32_t S = pick_splits(M, N, K, N > 64 ? 128 : 64);
+    return S > 1 ? (size_t)S * M * pad_ld(N) * sizeof(float) : 0;
 }
 
 template <int BN, int WM, int WN, int TM, int TN>
@@ -259,7 +263,8 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
         const size_t n = (size_t)g.M * g.ldc;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.C, scratch, g.M, g.N, g.ldc, S);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.C, scratch, g.M, g.N, g.ldc, S,
+                           g.epilogue == EPI_TANH ? g.C2 : (float *)nullptr, g.ldc2);
         e = hipGetLastError();
     }
     return e;

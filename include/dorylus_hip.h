@@ -188,6 +188,20 @@ int dory_timing_get(dory_ctx *ctx, const char *family, double *total_ms, uint64_
 int dory_timing_reset(dory_ctx *ctx);
 /* tuning knobs (e.g. "spmm_variant", "spmm_slab"); unknown keys are an error */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
+int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
+
+/* Epoch graph (MI355X-side addition, no reference counterpart): record the calls of one
+ * epoch -- dory_aggregate / dory_apply_vertex / dory_apply_edge / dory_predict_gat /
+ * dory_weight_update, exactly as Engine::runEpoch issues them -- into a hipGraph and replay
+ * it, so a launch-bound epoch costs one graph launch.  Single partition only; one eager epoch
+ * must have run before (lazy allocations).  Between begin and end the calls record instead of
+ * executing; dory_epoch_graph_launch(n) replays n epochs (asynchronously: dory_sync waits) and
+ * advances Adam's iteration count exactly as n eager epochs would (AdamOptimizer.cpp:29-34).
+ * dory_engine_run does all of this itself when the option "epoch_graph" is 1. */
+int dory_epoch_graph_begin(dory_ctx *ctx);
+int dory_epoch_graph_end(dory_ctx *ctx);
+int dory_epoch_graph_launch(dory_ctx *ctx, uint32_t epochs);
+int dory_epoch_graph_drop(dory_ctx *ctx);
 
 #ifdef __cplusplus
 }
