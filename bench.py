@@ -146,6 +146,8 @@ def main():
     if args.emulate:
         pr, pw = (int(t) for t in args.emulate.split("/"))
     parts = (np.arange(V, dtype=np.int64) * pw // V).astype(np.int32)   # contiguous blocks
+    if world > 1:   # every rank builds its own partition at the same time: share the host cores
+        os.environ.setdefault("DORY_BUILD_THREADS", str(max(1, min(32, usable_cpus() // world))))
     part = da.Partition.build(src, dst, parts, pr, pw)
     del src, dst
     g = part.view()
@@ -241,6 +243,17 @@ def main():
                 "algorithmic_bytes_per_launch": int(algo / launches_per_epoch),
                 "gather_bytes_per_launch": int((2 * nnz_in * 0 + (nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4) / 3)}
 
+    # second kernel family: the dense transforms on fp32 MFMA (all GEMMs of the epoch, split-K stages included)
+    gemm_ms, gemm_n = fam["gemm"]
+    d0, d1, d2 = (list(DIMS) + [0, 0, 0])[:3]
+    gemm_flops = 2.0 * N * (2 * d0 * d1 + 3 * d1 * d2) if len(DIMS) == 3 else 0.0   # z0, dW0 | z1, grad1, dW1
+    roofline_gemm = None
+    if gemm_ms > 0 and gemm_flops:
+        tf = gemm_flops * args.steps / (gemm_ms * 1e-3) / 1e12
+        roofline_gemm = {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 157.0, 4), "kernel": "gemm_kernel<BN,...> fp32 MFMA 32x32x2 (+ split-K reduce)",
+                         "flops_per_epoch": int(gemm_flops), "ms_per_epoch": round(gemm_ms / args.steps, 4)}
+
     # ---- CPU baseline: the oracle (port of the reference CPU path) on this box's cores ----------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate and args.workload == "reddit":
@@ -248,6 +261,7 @@ def main():
 
     if gat or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
+        roofline_gemm = None
     scale_name = {"reddit": "Reddit-scale"}.get(args.workload, args.workload + "-scale")
     if rank == 0:
         out = {
@@ -267,6 +281,7 @@ def main():
                        "partitioning": f"contiguous x{world}" + (f" (emulating rank {args.emulate}, no exchange)" if args.emulate else ""),
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
+            "roofline_gemm": roofline_gemm,
             "cpu_baseline": cpu,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
             "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1),
