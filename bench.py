@@ -50,6 +50,15 @@ def synth_edges(kind, V, E, seed=42):
         perm = rng.permutation(V).astype(np.uint32)
         s = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
         d = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
+    elif kind == "community":
+        # 50 equal communities of consecutive ids (what a METIS-ordered Reddit looks like to the
+        # kernels: subreddits): 85 % of the edges stay inside the source's community
+        C = 50
+        s = rng.integers(0, V, half, dtype=np.uint32)
+        size = (V + C - 1) // C
+        inside = rng.random(half) < 0.85
+        local = (s // size).astype(np.int64) * size + rng.integers(0, size, half)
+        d = np.where(inside, np.minimum(local, V - 1), rng.integers(0, V, half)).astype(np.uint32)
     else:
         raise ValueError(kind)
     return np.concatenate([s, d]), np.concatenate([d, s])
@@ -106,7 +115,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw"])
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "community"])
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
     ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS),
                     help="graph/model shape; anything but reddit is a scale test, not the BASELINE metric line")
@@ -115,6 +124,7 @@ def main():
                          "8-head per-edge-softmax extension (config 3's wording; no reference oracle); not the headline metric")
     ap.add_argument("--emulate", default="", help="R/P: run rank R's partition of a P-way split alone on one GPU, "
                     "halo exchange skipped (per-rank compute time of an N-GPU run; diagnostic, not the metric)")
+    ap.add_argument("--opt", nargs="*", default=[], help="context options key=value (diagnostic runs, e.g. spmm_variant=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows sampled for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -159,6 +169,9 @@ def main():
     ctx.configure({"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[args.gnn], DIMS, V, rank, world)
     if args.gnn == "gatmh":
         ctx.gatmh_heads([8, 1])
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     part.upload(ctx, parts if world > 1 else None)
     ctx.preallocate()
     # synthetic features: fp32 U(-1,1) keyed by global vertex id (same row whichever rank
@@ -233,7 +246,7 @@ def main():
     traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate and args.workload == "reddit":
+        if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate and args.workload == "reddit" and not args.opt:
             traffic = pm["spmm_variant_1"]["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass

@@ -57,25 +57,25 @@ struct Timed {
     Timed(dory_ctx *ctx, const char *family, hipStream_t st) : c(ctx), s(st), fam(family) {
         if (!c->timing || c->capturing) return;
         if (c->ev_pool.empty()) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
         } else {
             a = c->ev_pool.back().first;
             b = c->ev_pool.back().second;
             c->ev_pool.pop_back();
         }
-        hipEventRecord(a, s);
+        (void)hipEventRecord(a, s);
     }
     ~Timed() {
         if (!c->timing || c->capturing) return;
-        hipEventRecord(b, s);
+        (void)hipEventRecord(b, s);
         c->pending.push_back({fam, a, b});
     }
 };
 
 void drain_timing(dory_ctx *c) {
     for (auto &p : c->pending) {
-        hipEventSynchronize(p.b);
+        (void)hipEventSynchronize(p.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             c->times[p.fam].total_ms += ms;
@@ -113,7 +113,7 @@ Tensor *findw(std::vector<std::map<std::string, Tensor>> &tab, uint32_t layer, c
 void free_table(std::vector<std::map<std::string, Tensor>> &tab) {
     for (auto &m : tab)
         for (auto &kv : m)
-            if (kv.second.owned && kv.second.d) hipFree(kv.second.d);
+            if (kv.second.owned && kv.second.d) (void)hipFree(kv.second.d);
     tab.clear();
 }
 
@@ -130,7 +130,7 @@ int ensure_scratch(dory_ctx *c, size_t bytes) {
     if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: scratch would have to grow while recording (run one eager epoch first)");
     if (c->scratch) {
         HIPCK(c, hipStreamSynchronize(c->compute));
-        hipFree(c->scratch);
+        (void)hipFree(c->scratch);
         c->scratch = nullptr;
         c->scratch_bytes = 0;
     }
@@ -204,7 +204,7 @@ int dory_create(int device, dory_ctx **out) {
         delete c;
         return fail(nullptr, DORY_ERR_HIP, "stream/event creation failed");
     }
-    hipMemset(c->d_stat, 0, 2 * sizeof(float));
+    (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 1;      // 1: K1b source-blocked L2-resident gather where it applies, 0: K1 only
     c->opt["spmm_slab"] = 0;
@@ -221,7 +221,7 @@ int dory_create(int device, dory_ctx **out) {
 static void free_graph(dory_ctx *c) {
     void *ps[] = {c->colPtr, c->rowPtr, c->rowIdx, c->colIdx, c->cscVal, c->csrVal, c->norm, c->orderIn, c->orderOut};
     for (void *p : ps)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     c->colPtr = c->rowPtr = nullptr;
     c->rowIdx = c->colIdx = nullptr;
     c->cscVal = c->csrVal = c->norm = nullptr;
@@ -235,10 +235,10 @@ static void free_graph(dory_ctx *c) {
 
 int dory_destroy(dory_ctx *c) {
     if (!c) return DORY_ERR_ARG;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
     drain_timing(c);
-    for (auto &p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
     free_table(c->tensors);
     free_table(c->weights);
@@ -247,22 +247,22 @@ int dory_destroy(dory_ctx *c) {
     free_table(c->adam_v);
     free_graph(c);
     for (int d = 0; d < 2; ++d) {
-        if (c->plan[d].d_send_lvids) hipFree(c->plan[d].d_send_lvids);
-        if (c->plan[d].d_recv_slots) hipFree(c->plan[d].d_recv_slots);
+        if (c->plan[d].d_send_lvids) (void)hipFree(c->plan[d].d_send_lvids);
+        if (c->plan[d].d_recv_slots) (void)hipFree(c->plan[d].d_recv_slots);
     }
-    if (c->scratch) hipFree(c->scratch);
-    if (c->partial) hipFree(c->partial);
-    if (c->epoch_exec) hipGraphExecDestroy(c->epoch_exec);
-    if (c->epoch_graph) hipGraphDestroy(c->epoch_graph);
-    if (c->d_lr_table) hipFree(c->d_lr_table);
-    if (c->d_replay_idx) hipFree(c->d_replay_idx);
-    if (c->send_buf) hipFree(c->send_buf);
-    if (c->recv_buf) hipFree(c->recv_buf);
-    if (c->d_stat) hipFree(c->d_stat);
-    if (c->ev_a) hipEventDestroy(c->ev_a);
-    if (c->ev_b) hipEventDestroy(c->ev_b);
-    if (c->own_compute && c->compute) hipStreamDestroy(c->compute);
-    if (c->own_comm && c->comm) hipStreamDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->partial) (void)hipFree(c->partial);
+    if (c->epoch_exec) (void)hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) (void)hipGraphDestroy(c->epoch_graph);
+    if (c->d_lr_table) (void)hipFree(c->d_lr_table);
+    if (c->d_replay_idx) (void)hipFree(c->d_replay_idx);
+    if (c->send_buf) (void)hipFree(c->send_buf);
+    if (c->recv_buf) (void)hipFree(c->recv_buf);
+    if (c->d_stat) (void)hipFree(c->d_stat);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->own_compute && c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->own_comm && c->comm) (void)hipStreamDestroy(c->comm);
     delete c;
     return DORY_OK;
 }
@@ -273,12 +273,12 @@ int dory_set_streams(dory_ctx *c, void *compute_stream, void *comm_stream) {
     CHECK_CTX(c);
     HIPCK(c, hipDeviceSynchronize());
     if (compute_stream) {
-        if (c->own_compute) hipStreamDestroy(c->compute);
+        if (c->own_compute) (void)hipStreamDestroy(c->compute);
         c->compute = (hipStream_t)compute_stream;
         c->own_compute = false;
     }
     if (comm_stream) {
-        if (c->own_comm) hipStreamDestroy(c->comm);
+        if (c->own_comm) (void)hipStreamDestroy(c->comm);
         c->comm = (hipStream_t)comm_stream;
         c->own_comm = false;
     }
@@ -475,7 +475,7 @@ int dory_preallocate(dory_ctx *c) {
             const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
             const size_t need = (size_t)nbmax * N * maxld * sizeof(float);
             if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
-                if (c->partial) hipFree(c->partial);
+                if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;
                 c->partial_bytes = 0;
                 HIPCK(c, hipMalloc((void **)&c->partial, need));
@@ -511,7 +511,7 @@ static int upload_dense(dory_ctx *c, Tensor &t, const float *host) {
         HIPCK(c, hipMemcpyAsync(stage, host, b, hipMemcpyHostToDevice, c->compute));
         HIPCK(c, launch_pad_copy(t.d, t.ld, stage, t.cols, t.rows, t.cols, c->compute));
         HIPCK(c, hipStreamSynchronize(c->compute));
-        hipFree(stage);
+        (void)hipFree(stage);
     }
     HIPCK(c, hipStreamSynchronize(c->compute));
     return DORY_OK;
@@ -561,7 +561,7 @@ int dory_tensor_fill_uniform(dory_ctx *c, uint32_t layer, const char *name, uint
     }
     HIPCK(c, launch_fill_uniform_ids(t->d, t->rows, t->cols, t->ld, ids, seed, lo, hi, c->compute));
     HIPCK(c, hipStreamSynchronize(c->compute));
-    if (ids) hipFree(ids);
+    if (ids) (void)hipFree(ids);
     return DORY_OK;
 }
 
@@ -577,7 +577,7 @@ int dory_labels_upload(dory_ctx *c, const uint32_t *labels) {
     if (rc) return rc;
     HIPCK(c, launch_onehot(t->d, t->rows, t->cols, t->ld, dl, c->compute));
     HIPCK(c, hipStreamSynchronize(c->compute));
-    hipFree(dl);
+    (void)hipFree(dl);
     return DORY_OK;
 }
 
@@ -694,7 +694,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             if (need > c->partial_bytes) {
                 if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: partial buffer would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));
-                if (c->partial) hipFree(c->partial);
+                if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;
                 c->partial_bytes = 0;
                 HIPCK(c, hipMalloc((void **)&c->partial, need));
@@ -1011,8 +1011,8 @@ int dory_halo_plan(dory_ctx *c, int dir, const uint32_t *send_counts, const uint
         if (recv_slots[i] >= G || seen[recv_slots[i]]) return fail(c, DORY_ERR_ARG, "halo_plan: recv slots must be a permutation of the ghost slots");
         seen[recv_slots[i]] = 1;
     }
-    if (p.d_send_lvids) hipFree(p.d_send_lvids);
-    if (p.d_recv_slots) hipFree(p.d_recv_slots);
+    if (p.d_send_lvids) (void)hipFree(p.d_send_lvids);
+    if (p.d_recv_slots) (void)hipFree(p.d_recv_slots);
     p.d_send_lvids = p.d_recv_slots = nullptr;
     int rc;
     if ((rc = upload_array(c, &p.d_send_lvids, send_lvids, p.send_total))) return rc;
@@ -1101,13 +1101,13 @@ int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
     const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
     if (sb > c->send_cap) {
         HIPCK(c, hipDeviceSynchronize());
-        if (c->send_buf) hipFree(c->send_buf);
+        if (c->send_buf) (void)hipFree(c->send_buf);
         HIPCK(c, hipMalloc((void **)&c->send_buf, sb));
         c->send_cap = sb;
     }
     if (rb > c->recv_cap) {
         HIPCK(c, hipDeviceSynchronize());
-        if (c->recv_buf) hipFree(c->recv_buf);
+        if (c->recv_buf) (void)hipFree(c->recv_buf);
         HIPCK(c, hipMalloc((void **)&c->recv_buf, rb));
         c->recv_cap = rb;
     }
@@ -1235,12 +1235,12 @@ static float adam_lr_t(const dory_ctx *c, unsigned epochs) {   // AdamOptimizer:
 static void epoch_graph_drop_locked(dory_ctx *c) {
     if (c->capturing) {   // abandon a recording in progress
         hipGraph_t g = nullptr;
-        hipStreamEndCapture(c->compute, &g);
-        if (g) hipGraphDestroy(g);
+        (void)hipStreamEndCapture(c->compute, &g);
+        if (g) (void)hipGraphDestroy(g);
         c->capturing = false;
     }
-    if (c->epoch_exec) hipGraphExecDestroy(c->epoch_exec);
-    if (c->epoch_graph) hipGraphDestroy(c->epoch_graph);
+    if (c->epoch_exec) (void)hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) (void)hipGraphDestroy(c->epoch_graph);
     c->epoch_exec = nullptr;
     c->epoch_graph = nullptr;
     c->lr_table_left = 0;
@@ -1277,7 +1277,7 @@ int dory_epoch_graph_end(dory_ctx *c) {
     hipError_t e2 = hipStreamEndCapture(c->compute, &g);
     c->capturing = false;
     if (e != hipSuccess || e2 != hipSuccess || !g) {
-        if (g) hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
         return fail(c, DORY_ERR_HIP, "epoch_graph_end: recording failed (%s)", hipGetErrorString(e != hipSuccess ? e : e2));
     }
     c->epoch_graph = g;

@@ -305,18 +305,18 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
                        B.bbase, B.boff, cnt, B.bidx, B.bval);
     BCK(hipGetLastError());
     BCK(hipStreamSynchronize(s));
-    hipFree(cnt);
-    hipFree(dtotal);
+    (void)hipFree(cnt);
+    (void)hipFree(dtotal);
 #undef BCK
     *out = B;
     return hipSuccess;
 }
 
 void free_blocked(BlockedAdj *B) {
-    if (B->boff) hipFree(B->boff);
-    if (B->bbase) hipFree(B->bbase);
-    if (B->bidx) hipFree(B->bidx);
-    if (B->bval) hipFree(B->bval);
+    if (B->boff) (void)hipFree(B->boff);
+    if (B->bbase) (void)hipFree(B->bbase);
+    if (B->bidx) (void)hipFree(B->bidx);
+    if (B->bval) (void)hipFree(B->bval);
     *B = BlockedAdj{};
 }
 
