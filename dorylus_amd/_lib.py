@@ -98,6 +98,8 @@ def load():
         "dory_engine_run": [vp, u32, vp],
         "dory_engine_nn_compute": [vp, vp],
         "dory_engine_inc_layer": [vp, vp, vp],
+        "dory_chunk_inc_layer": [i32, u32, vp, vp],
+        "dory_engine_trace_epoch": [i32, u32, C.c_char_p, C.c_size_t],
         "dory_engine_is_last_layer": [vp, vp],
         "dory_engine_report": [vp, cp, C.c_size_t],
     }

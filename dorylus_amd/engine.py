@@ -118,6 +118,9 @@ class Engine:
     def run_epoch(self, epoch=1):
         N = getattr(self.ctx, "N", 0)
         c = Chunk(0, 0, 0, N, 0, FORWARD, epoch, True)
+        if self.gnn_type == GCN and self.numLayers < 2:
+            # engine/utils.cpp:707-727: a one-layer GCN chunk never satisfies isLastLayer (host/engine.cpp refuses too)
+            raise DoryError("GCN needs at least 2 layers: the reference's layer state machine has no epoch boundary otherwise")
         if self.gnn_type == GCN:
             while True:
                 self.aggregateGCN(c)                       # GA

@@ -39,9 +39,17 @@ class ResourceComm {
 // (GPU_comm.cpp:11-35) are for the cpu / gpu builds.
 class HIPComm : public ResourceComm {
   public:
-    HIPComm(dory_ctx *ctx, int gnn, unsigned totalLayers) : ctx_(ctx), gnn_(gnn), totalLayers_(totalLayers) {}
+    HIPComm(dory_ctx *ctx, int gnn, unsigned totalLayers, std::vector<std::string> *trace = nullptr)
+        : ctx_(ctx), gnn_(gnn), totalLayers_(totalLayers), trace_(trace) {}
     int NNCompute(Chunk &chunk) override {
         int rc;
+        if (trace_) {   // dry run (dory_engine_trace_epoch): the same decisions, names instead of launches
+            const bool produced = chunk.vertex && (gnn_ == DORY_GCN ? (chunk.dir == DORY_BACKWARD || chunk.layer == totalLayers_ - 1)
+                                                                    : (chunk.dir == DORY_BACKWARD));
+            trace_->push_back(stage_name(chunk.vertex ? "AV" : "AE", chunk.layer, chunk.dir));
+            if (produced) trace_->push_back("WU" + std::to_string(chunk.layer));
+            return DORY_OK;
+        }
         if (chunk.vertex) {
             if ((rc = dory_apply_vertex(ctx_, chunk.layer, chunk.dir))) return rc;
             // sendWeightUpdate (CPU_comm.cpp:131,147,178): the gradient leaves for the
@@ -56,17 +64,23 @@ class HIPComm : public ResourceComm {
         return dory_apply_edge(ctx_, chunk.layer, chunk.dir);  // layer-- happens inside (CPU_comm.cpp:33)
     }
 
+    static std::string stage_name(const char *stage, unsigned layer, int dir) {
+        return std::string(stage) + std::to_string(layer) + (dir == DORY_FORWARD ? "F" : "B");
+    }
+
   private:
     dory_ctx *ctx_;
     int gnn_;
     unsigned totalLayers_;
+    std::vector<std::string> *trace_;
 };
 
 class Engine {
   public:
-    Engine(dory_ctx *ctx, int gnn, unsigned numLayers, unsigned nodeId, unsigned localVtxCnt)
+    Engine(dory_ctx *ctx, int gnn, unsigned numLayers, unsigned nodeId, unsigned localVtxCnt,
+           std::vector<std::string> *trace = nullptr)
         : ctx(ctx), gnn_type(gnn), numLayers(numLayers), nodeId(nodeId), localVtxCnt(localVtxCnt),
-          resComm(new HIPComm(ctx, gnn, numLayers)) {}
+          resComm(new HIPComm(ctx, gnn, numLayers, trace)), trace(trace) {}
     ~Engine() { delete resComm; }
 
     // ---- layer utils (engine/utils.cpp:707-753) ------------------------------------
@@ -107,8 +121,15 @@ class Engine {
     bool isLastLayer(const Chunk &c) const { return c.dir == DORY_BACKWARD && c.layer == 0 && c.vertex; }
 
     // ---- SAGA stages -----------------------------------------------------------------
-    int aggregateGCN(Chunk &c) { return dory_aggregate(ctx, c.layer, c.dir); }   // gcn_ops.cpp:130-191
-    int aggregateGAT(Chunk &c) { return dory_aggregate(ctx, c.layer, c.dir); }   // gat_ops.cpp:173-243
+    int stage(const char *name, const Chunk &c, int (*call)(dory_ctx *, uint32_t, int)) {
+        if (trace) {
+            trace->push_back(HIPComm::stage_name(name, c.layer, c.dir));
+            return DORY_OK;
+        }
+        return call(ctx, c.layer, c.dir);
+    }
+    int aggregateGCN(Chunk &c) { return stage("GA", c, dory_aggregate); }   // gcn_ops.cpp:130-191
+    int aggregateGAT(Chunk &c) { return stage("GA", c, dory_aggregate); }   // gat_ops.cpp:173-243
     int applyVertexGCN(Chunk &c) {                                               // gcn_ops.cpp:194-202
         c.vertex = true;
         if (c.dir == DORY_FORWARD) return resComm->NNCompute(c);
@@ -125,19 +146,29 @@ class Engine {
         c = nextC;
         return rc;
     }
-    int scatterGCN(Chunk &c) { return dory_halo_exchange(ctx, c.layer, c.dir); }  // gcn_ops.cpp:204-362
-    int scatterGAT(Chunk &c) { return dory_halo_exchange(ctx, c.layer, c.dir); }  // gat_ops.cpp:277-435
+    int scatterGCN(Chunk &c) { return stage("SC", c, dory_halo_exchange); }  // gcn_ops.cpp:204-362
+    int scatterGAT(Chunk &c) { return stage("SC", c, dory_halo_exchange); }  // gat_ops.cpp:277-435
     int applyEdgeGAT(Chunk &c) {                                                  // gat_ops.cpp:437-440
         c.vertex = false;
         return resComm->NNCompute(c);
     }
-    int predictGAT(Chunk &c) { return dory_predict_gat(ctx, c.layer); }           // gat_ops.cpp:246-265
+    int predictGAT(Chunk &c) {                                                    // gat_ops.cpp:246-265
+        if (trace) {
+            trace->push_back("PR" + std::to_string(c.layer));
+            return DORY_OK;
+        }
+        return dory_predict_gat(ctx, c.layer);
+    }
 
     // One synchronous epoch: the path a chunk takes through the queues
     // (ops/pipeline.cpp:170-173,183-219,262-342; resource_comm.cpp:17-51,53-90).
     int runEpoch(unsigned epoch) {
         Chunk c{0, nodeId, 0, localVtxCnt, 0, DORY_FORWARD, epoch, true};
         int rc;
+        // a one-layer GCN never reaches isLastLayer in this state machine (its only forward layer
+        // merges into a backward pass that re-enters the forward one, engine/utils.cpp:707-727):
+        // the reference would spin through epochs without a boundary; refuse instead
+        if (gnn_type == DORY_GCN && numLayers < 2) return DORY_ERR_ARG;
         if (gnn_type == DORY_GCN) {
             for (;;) {
                 if ((rc = aggregateGCN(c))) return rc;          // GA
@@ -171,6 +202,7 @@ class Engine {
     int gnn_type;
     unsigned numLayers, nodeId, localVtxCnt;
     ResourceComm *resComm;
+    std::vector<std::string> *trace;   // dry run: stage names instead of C-ABI calls
     std::vector<double> epochTimes;
 };
 
@@ -271,6 +303,28 @@ int dory_engine_is_last_layer(dory_engine *e, const struct dory_chunk *in) {
     if (!e || !in) return DORY_ERR_ARG;
     dorylus::Chunk c{in->localId, in->globalId, in->lowBound, in->upBound, in->layer, in->dir, in->epoch, in->vertex != 0};
     return e->eng->isLastLayer(c) ? 1 : 0;
+}
+
+int dory_engine_trace_epoch(int gnn_type, uint32_t num_layers, char *buf, size_t buflen) {
+    if ((gnn_type != DORY_GCN && gnn_type != DORY_GAT) || num_layers == 0 || !buf || buflen == 0) return DORY_ERR_ARG;
+    std::vector<std::string> tr;
+    dorylus::Engine eng(nullptr, gnn_type, num_layers, 0, 0, &tr);
+    int rc = eng.runEpoch(1);
+    if (rc) return rc;
+    std::string out;
+    for (size_t i = 0; i < tr.size(); ++i) out += (i ? " " : "") + tr[i];
+    if (out.size() + 1 > buflen) return DORY_ERR_ARG;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return DORY_OK;
+}
+
+int dory_chunk_inc_layer(int gnn_type, uint32_t num_layers, const struct dory_chunk *in, struct dory_chunk *out) {
+    if ((gnn_type != DORY_GCN && gnn_type != DORY_GAT) || num_layers == 0 || !in || !out) return DORY_ERR_ARG;
+    dorylus::Engine eng(nullptr, gnn_type, num_layers, 0, 0);
+    dorylus::Chunk c{in->localId, in->globalId, in->lowBound, in->upBound, in->layer, in->dir, in->epoch, in->vertex != 0};
+    dorylus::Chunk n = eng.incLayer(c);
+    *out = dory_chunk{n.localId, n.globalId, n.lowBound, n.upBound, n.layer, n.dir, n.epoch, (uint8_t)n.vertex};
+    return DORY_OK;
 }
 
 int dory_engine_report(dory_engine *e, char *buf, size_t buflen) {

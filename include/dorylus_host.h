@@ -101,6 +101,14 @@ struct dory_chunk { /* common/utils.hpp:64-75 */
 int dory_engine_nn_compute(dory_engine *e, struct dory_chunk *chunk);   /* ResourceComm::NNCompute */
 int dory_engine_inc_layer(dory_engine *e, const struct dory_chunk *in, struct dory_chunk *out); /* incLayerGCN/GAT */
 int dory_engine_is_last_layer(dory_engine *e, const struct dory_chunk *c);
+/* The same state machine without an engine or a device (engine/utils.cpp:707-753): next chunk of `in`. */
+int dory_chunk_inc_layer(int gnn_type, uint32_t num_layers, const struct dory_chunk *in, struct dory_chunk *out);
+/* Dry run of one synchronous epoch: the stages Engine::runEpoch would issue, as space-separated names
+ * "<stage><layer><F|B>" with stage GA (aggregate), AV (applyVertex -> NNCompute), AE (applyEdge), SC (scatter),
+ * plus "WU<layer>" (weight update sent, CPU_comm.cpp:131,147,178) and "PR<layer>" (predictGAT); no device needed.
+ * The order is the one a chunk takes through the reference's queues (ops/pipeline.cpp:170-342,
+ * resource_comm.cpp:17-90). */
+int dory_engine_trace_epoch(int gnn_type, uint32_t num_layers, char *buf, size_t buflen);
 /* "<EM>: ..." style report of the last run into buf (engine/utils.cpp:219-291) */
 int dory_engine_report(dory_engine *e, char *buf, size_t buflen);
 
