@@ -227,6 +227,9 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     nl = len(DIMS) - 1
     edges_per_epoch = nl * E_in + (nl - 1) * E_out           # L forward (CSC) + L-1 backward (CSR) aggregations
+    tf_mode = (not gat) and ctx.transform_first_active()          # diagnostic: A(XW0) order, one more d1-wide CSR pass for dW0
+    if tf_mode:
+        edges_per_epoch = nl * E_in + nl * E_out
     if gat:                                                  # 2 fwd (CSC) + 2 bwd x (CSR + CSC) aggregations
         edges_per_epoch = 4 * E_in + 2 * E_out               # (gatmh: softmax passes re-walk the edges; same count used)
     value = edges_per_epoch / (ms_per_step * 1e-3)
@@ -272,7 +275,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate and args.workload == "reddit":
         cpu = cpu_baseline(ctx, g, args.cpu_rows)
 
-    if gat or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
+    if gat or tf_mode or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
         roofline_gemm = None
     scale_name = {"reddit": "Reddit-scale"}.get(args.workload, args.workload + "-scale")
@@ -290,7 +293,8 @@ def main():
                                     "Reddit GCN 2-layer (232965 verts, ~114.6M edges, feat 602-128-41) full-graph"
                                     if args.workload == "reddit" else
                                     f"{args.workload} GCN {len(DIMS) - 1}-layer ({V} verts, feat {'-'.join(map(str, DIMS))}) scale test"),
-                       "graph": args.graph, "vertices": V, "edges": E_in,
+                       "graph": args.graph, "vertices": V, "edges": E_in, "options": args.opt or None,
+                       "layer0_order": "transform-first A(XW) [opt-in, not the reference order]" if tf_mode else "aggregate-first (AX)W",
                        "partitioning": f"contiguous x{world}" + (f" (emulating rank {args.emulate}, no exchange)" if args.emulate else ""),
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,

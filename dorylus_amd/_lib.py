@@ -23,7 +23,7 @@ SYMBOLS = [
     "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
-    "dory_gatmh_heads",
+    "dory_gatmh_heads", "dory_transform_first_active",
 ]
 
 FORWARD, BACKWARD = 0, 1
@@ -77,6 +77,7 @@ def load():
         "dory_timing_reset": [vp],
         "dory_set_option": [vp, cp, C.c_int64],
         "dory_get_option": [vp, cp, C.POINTER(C.c_int64)],
+        "dory_transform_first_active": [vp],
         "dory_epoch_graph_begin": [vp], "dory_epoch_graph_end": [vp], "dory_epoch_graph_launch": [vp, u32],
         "dory_epoch_graph_drop": [vp],
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
@@ -310,6 +311,9 @@ class Context:
 
     def set_option(self, key, value):
         self._ck(self.lib.dory_set_option(self.h, key.encode(), int(value)))
+
+    def transform_first_active(self):
+        return bool(self.lib.dory_transform_first_active(self.h))
 
     def get_option(self, key):
         v = C.c_int64(0)

@@ -179,6 +179,14 @@ static int wait_halo(dory_ctx *c) {
     return DORY_OK;
 }
 
+// Transform-first order for GCN layer 0 (opt-in, no reference counterpart): A(XW0) gathers d1-wide rows
+// instead of the d0-wide rows of (AX)W0 -- 128 instead of 602 floats per edge on Reddit.  The weight gradient
+// follows as X^T(A^T g0): one more d1-wide SpMM on the out-edges.  "ah"@0 is not produced in this mode.
+static bool tf_active(dory_ctx *c) {
+    return c->gnn == DORY_GCN && c->L >= 2 && c->dims[0] > c->dims[1] && c->opt["gcn_transform_first"] != 0 &&
+           c->opt["adjacency_values_asymmetric"] == 0;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------
@@ -212,6 +220,8 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
+    c->opt["gcn_transform_first"] = 0;   // GCN layer 0 as A(XW) instead of (AX)W when the input is wider than the output (see tf_active)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
@@ -388,6 +398,12 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "grad", N, d[l]);
             mk(l - 1, "bg", c->Gdst, d[l]);
             mk(l - 1, "aTg", N, d[l]);
+        }
+        if (L >= 2 && d[0] > d[1]) {   // transform-first order of layer 0 (option gcn_transform_first)
+            mk(0, "xw", N, d[1]);          // X W0
+            mk(0, "fgxw", c->Gsrc, d[1]);  // the same for the layer-0 ghost rows
+            mk(0, "u", N, d[1]);           // A^T g0
+            mk(0, "bgg", c->Gdst, d[1]);   // ghost rows of g0 (backward exchange at layer 0)
         }
     } else if (c->gnn == DORY_GATMH) {  // extension (no reference counterpart): see dory_gatmh_heads
         if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only in this version");
@@ -741,7 +757,21 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             NEED(fg, layer, "fg");
             NEED(ah, layer, "ah");
             if (!in) return fail(c, DORY_ERR_ARG, "aggregate: input tensor missing");
+            if (layer == 0 && tf_active(c)) {   // z0 = A (X W0): transform the local and the ghost rows, then gather d1-wide
+                NEED(xw, 0, "xw"); NEED(fgxw, 0, "fgxw"); NEED(z, 0, "z");
+                Tensor &W = c->weights[0]["w"];
+                int rc = gemm(c, 0, 0, c->N, c->dims[1], c->dims[0], *in, W, *xw);
+                if (!rc && c->Gsrc) rc = gemm(c, 0, 0, c->Gsrc, c->dims[1], c->dims[0], *fg, W, *fgxw);
+                if (rc) return rc;
+                return spmm(c, true, c->cscVal, 1, *xw, fgxw, *z, c->dims[1], 0);
+            }
             return spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+        }
+        if (layer == 0 && tf_active(c)) {   // dW0 = X^T (A^T g0)   (ghost rows of g0: halo exchange (0, backward))
+            NEED(g, 0, "g"); NEED(bgg, 0, "bgg"); NEED(u, 0, "u"); NEED(x, 0, "x");
+            int rc = spmm(c, false, c->csrVal, 1, *g, bgg, *u, c->dims[1], 0);
+            if (rc) return rc;
+            return gemm(c, 1, 0, c->dims[0], c->dims[1], c->N, *x, *u, c->wgrads[0]["w"]);
         }
         if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "aggregate backward: layer %u out of range", layer);
         NEED(grad, layer, "grad");
@@ -832,6 +862,11 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
         if (dir == DORY_FORWARD) {
             if (layer != c->L - 1) {  // vtxNNForwardGCN hidden (CPU_comm.cpp:98-107)
                 NEED(h, layer, "h");
+                if (layer == 0 && tf_active(c)) {   // z0 came out of dory_aggregate already
+                    Timed t(c, "loss", c->compute);
+                    HIPCK(c, launch_tanh_forward(N, Fout, z->d, z->ld, h->d, h->ld, c->compute));
+                    return DORY_OK;
+                }
                 return gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z, h);
             }
             // last layer (CPU_comm.cpp:108-133)
@@ -861,6 +896,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
             Timed t(c, "loss", c->compute);
             HIPCK(c, launch_tanh_backward(N, Fout, aTg->d, aTg->ld, z->d, z->ld, g->d, g->ld, c->compute));
         }
+        if (layer == 0 && tf_active(c)) return DORY_OK;   // dW0 follows in dory_aggregate(0, backward)
         if ((rc = gemm(c, 1, 0, Fin, Fout, N, *ah, *g, dW))) return rc;
         if (layer != 0) {
             NEED(grad, layer, "grad");
@@ -1046,7 +1082,10 @@ int dory_comm_init(dory_ctx *c, const void *id128, int rank, int nranks) {
 
 // resolve (layer, dir) -> source tensor, ghost tensor, width, as Engine::scatterGCN/GAT do
 static int halo_tensors(dory_ctx *c, uint32_t layer, int dir, Tensor **src, Tensor **ghost) {
-    if (c->gnn == DORY_GCN) {
+    if (c->gnn == DORY_GCN && layer == 0 && dir == DORY_BACKWARD && tf_active(c)) {
+        *src = find(c, 0, "g");      // transform-first: A^T g0 needs the ghost rows of g0
+        *ghost = find(c, 0, "bgg");
+    } else if (c->gnn == DORY_GCN) {
         if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "halo: layer %u out of range", layer);
         if (dir == DORY_FORWARD) { *src = find(c, layer - 1, "h"); *ghost = find(c, layer, "fg"); }   // gcn_ops.cpp:205-214
         else { *src = find(c, layer, "grad"); *ghost = find(c, layer - 1, "bg"); }
@@ -1309,6 +1348,12 @@ int dory_epoch_graph_launch(dory_ctx *c, uint32_t epochs) {
         c->adam.epochs += 1;
     }
     return DORY_OK;
+}
+
+int dory_transform_first_active(dory_ctx *c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    return c->configured && tf_active(c) ? 1 : 0;
 }
 
 int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {

@@ -188,6 +188,8 @@ size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K);
 // K3/K4 elementwise + loss
 hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, uint32_t lda,
                                 const float *z, uint32_t ldz, float *g, uint32_t ldg, hipStream_t s);
+hipError_t launch_tanh_forward(uint64_t rows, uint32_t cols, const float *z, uint32_t ldz, float *h, uint32_t ldh,
+                               hipStream_t s);
 // softmax + validation stats + maskout quirk + (p - lab)/denom  (CPU_comm.cpp:108-122)
 hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
                                const float *lab, uint32_t ldl, float *d, uint32_t ldd,

@@ -51,6 +51,25 @@ hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, 
     return hipGetLastError();
 }
 
+// h = tanh(z) on its own: the transform-first order computes z with the SpMM, not the GEMM whose
+// epilogue normally applies the activation (same tanhf as that epilogue)
+__global__ void tanh_forward_kernel(uint64_t rows, uint32_t cols, const float *z, uint32_t ldz, float *h, uint32_t ldh) {
+    const uint64_t n = rows * cols;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / cols;
+        const uint32_t c = (uint32_t)(i % cols);
+        h[r * ldh + c] = tanhf(z[r * ldz + c]);
+    }
+}
+hipError_t launch_tanh_forward(uint64_t rows, uint32_t cols, const float *z, uint32_t ldz, float *h, uint32_t ldh,
+                               hipStream_t s) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    const uint64_t n = rows * cols;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tanh_forward_kernel, dim3(blocks), dim3(256), 0, s, rows, cols, z, ldz, h, ldh);
+    return hipGetLastError();
+}
+
 // ---- K4: softmax + maskout quirk + (p - lab) / denom  ---------------------------
 // softmax (CPU_comm.cpp:276-297: max-subtracted, denominator seeded with 1e-20),
 // maskout (CPU_comm.cpp:464-471: copies (rows - stt) FLOATS of the dense label

@@ -221,6 +221,7 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
 
 static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
     const uint32_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    if (tiles == 0) return 1;
     // a workgroup walks its k-tiles one after the other (~1.9 us each): with few tiles even a
     // Cora-sized K (2 708 rows -> 85 k-tiles = 160 us on one workgroup) wants to be split
     if (tiles >= 512 || K < 8 * BK) return 1;
@@ -239,6 +240,12 @@ size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K) {
 
 template <int BN, int WM, int WN, int TM, int TN>
 static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
+    if (g.K == 0) {   // empty partition: the product of an M x 0 and a 0 x N matrix is all zeros (tanh(0) = 0 too)
+        hipError_t e = hipMemsetAsync(g.C, 0, (size_t)g.M * g.ldc * sizeof(float), s);
+        if (e == hipSuccess && g.epilogue == EPI_TANH && g.C2)
+            e = hipMemsetAsync(g.C2, 0, (size_t)g.M * g.ldc2 * sizeof(float), s);
+        return e;
+    }
     uint32_t S = pick_splits(g.M, g.N, g.K, BN);
     if (S > 1 && (size_t)S * g.M * g.ldc * sizeof(float) > scratch_bytes) {
         S = (uint32_t)(scratch_bytes / ((size_t)g.M * g.ldc * sizeof(float)));

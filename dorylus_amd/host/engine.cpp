@@ -58,6 +58,8 @@ class HIPComm : public ResourceComm {
             bool produced = gnn_ == DORY_GCN
                                 ? (chunk.dir == DORY_BACKWARD || chunk.layer == totalLayers_ - 1)
                                 : (chunk.dir == DORY_BACKWARD);
+            // transform-first order: dW0 only exists after the extra aggregation Engine::runEpoch issues
+            if (produced && chunk.layer == 0 && chunk.dir == DORY_BACKWARD && dory_transform_first_active(ctx_)) produced = false;
             if (produced && (rc = dory_weight_update(ctx_, chunk.layer))) return rc;
             return DORY_OK;
         }
@@ -173,7 +175,16 @@ class Engine {
             for (;;) {
                 if ((rc = aggregateGCN(c))) return rc;          // GA
                 if ((rc = applyVertexGCN(c))) return rc;        // AV -> NNRecvCallbackGCN
-                if (isLastLayer(c)) break;                      //   -> schQueue (next epoch)
+                if (isLastLayer(c)) {                           //   -> schQueue (next epoch)
+                    if (!trace && dory_transform_first_active(ctx)) {
+                        // transform-first order of layer 0 (dorylus_hip.h): dW0 = X^T (A^T g0) needs g0's ghost
+                        // rows and one more aggregation on the out-edges before the update can leave
+                        if ((rc = scatterGCN(c))) return rc;
+                        if ((rc = aggregateGCN(c))) return rc;
+                        if ((rc = dory_weight_update(ctx, 0))) return rc;
+                    }
+                    break;
+                }
                 if (c.dir == DORY_FORWARD) c = incLayerGCN(c);  //   forward: inc layer after AV
                 if ((rc = scatterGCN(c))) return rc;            // SC (+ ghostReceiver, barrier)
                 // AE: applyEdgeGCN forwards to GA (gcn_ops.cpp:364-366)

@@ -31,6 +31,10 @@ struct dory_partition {
     std::vector<uint64_t> colPtr, rowPtr;
     std::vector<uint32_t> rowIdx, colIdx;
     std::vector<float> cscVal, csrVal;
+    // 0: built from directed records -> csrVal is exactly cscVal transposed (across partitions too);
+    // 1: built with undirected = 1 -> ghost norms count file records only (dataloader.cpp:192-218), so the
+    //    values of one edge differ between its two owners;  -1: read from graph.<id>.bin, unknown
+    int undirected = -1;
 };
 
 static thread_local std::string g_err;
@@ -56,6 +60,7 @@ int dory_partition_build(const uint32_t *src, const uint32_t *dst, uint64_t nrec
     dory_partition &g = *pp;
     g.V = V;
     g.P = P;
+    g.undirected = undirected ? 1 : 0;
 
     // readPartsFile (dataloader.cpp:53-87): local ids ascend with global id
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -420,7 +425,10 @@ int dory_partition_upload(dory_ctx *ctx, const dory_partition *p, const int32_t 
     int rc = dory_graph_upload(ctx, p->N, p->Gsrc, p->Gdst, p->nin, p->colPtr.data(), p->rowIdx.data(),
                                p->cscVal.data(), p->nout, p->rowPtr.data(), p->colIdx.data(),
                                p->csrVal.data(), p->norm.data());
-    if (rc || !parts || p->P <= 1) return rc;
+    if (rc) return rc;
+    // the transform-first GCN order needs csrVal == cscVal transposed: only known for directed builds
+    if ((rc = dory_set_option(ctx, "adjacency_values_asymmetric", p->undirected == 0 ? 0 : 1))) return rc;
+    if (!parts || p->P <= 1) return rc;
     // receive side of the plan: peer q's k-th row lands in the k-th ghost slot owned by q
     for (int dir = 0; dir < 2; ++dir) {
         const std::vector<uint32_t> &ghost = dir == 0 ? p->srcGhost : p->dstGhost;

@@ -190,6 +190,20 @@ int dory_timing_reset(dory_ctx *ctx);
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
 
+/* Transform-first order of GCN layer 0 (option "gcn_transform_first" = 1; no reference counterpart): when the
+ * input is wider than the first hidden layer, z0 = A (X W0) instead of (A X) W0, i.e. the aggregation gathers
+ * dims[1]-wide rows, and dW0 = X^T (A^T g0).  Same z0, h0, dW0 within fp32 rounding; "ah"@0 is not produced.
+ * Stage meaning in this mode: dory_aggregate(0, FORWARD) writes "z"@0; dory_apply_vertex(0, FORWARD) only applies
+ * tanh; dory_apply_vertex(0, BACKWARD) only forms g0; dory_halo_exchange(0, BACKWARD) ships g0's ghost rows;
+ * dory_aggregate(0, BACKWARD) forms dW0 -- call dory_weight_update(0) after it.  dory_engine_run follows this
+ * order by itself.  Precondition: the backward adjacency values are the forward ones transposed, which holds for
+ * partitions built from directed records (the reference datasets are stored symmetrised and run with
+ * --undirected 0, run/run-onnode:46); with --undirected 1 the reference counts ghost degrees from file records
+ * only (dataloader.cpp:192-218) and the two owners of an edge disagree on its value: dory_partition_upload then
+ * sets the option "adjacency_values_asymmetric" and the mode stays off (a direct dory_graph_upload caller sets it
+ * itself).  Returns 1 when the mode applies to the configured model and graph, else 0. */
+int dory_transform_first_active(dory_ctx *ctx);
+
 /* Epoch graph (MI355X-side addition, no reference counterpart): record the calls of one
  * epoch -- dory_aggregate / dory_apply_vertex / dory_apply_edge / dory_predict_gat /
  * dory_weight_update, exactly as Engine::runEpoch issues them -- into a hipGraph and replay

@@ -136,7 +136,7 @@ def test_aggregate_feature_slabs(da, slab):
     ctx.close()
 
 
-def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None):
+def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None, transform_first=False):
     """P partitions as P contexts on one GPU; the transport between them is a host
     copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
     import torch
@@ -153,6 +153,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
         for l, W in enumerate(Ws):
             ctx.weight_set(l, "w", W)
         ctx.adam_config(lr)
+        ctx.set_option("gcn_transform_first", int(transform_first))
         pl = halo_plan(g, parts, r, P)
         if native_plan is not None:
             # the C++ path bench.py / graphserver use: dory_partition_upload computes both plans
@@ -166,7 +167,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
 
     def exchange(layer, d):
         # widths travel padded (ld); transport = device-to-device copies by torch
-        src_name, src_layer = ("h", layer - 1) if d == 0 else ("grad", layer)
+        src_name, src_layer = ("h", layer - 1) if d == 0 else ("grad", layer) if layer > 0 else ("g", 0)
         _, _, ld, _ = ctxs[0].info(src_layer, src_name)
         send = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][0])) * ld, device="cuda") for r in range(P)]
         recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][1])) * ld, device="cuda") for r in range(P)]
@@ -202,6 +203,10 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
             for c in ctxs:
                 c.aggregate(l, da.BACKWARD)
                 c.apply_vertex(l - 1, da.BACKWARD)
+            if l == 1 and ctxs[0].transform_first_active():
+                exchange(0, da.BACKWARD)              # ghost rows of g0
+                for c in ctxs:
+                    c.aggregate(0, da.BACKWARD)       # dW0 = X^T (A^T g0)
             dWs[l - 1] = sum(c.weight_grad_get(l - 1) for c in ctxs)
         if epochs > 1:
             for c in ctxs:
@@ -268,6 +273,91 @@ def test_gcn_epoch_vs_oracle(da, case, dims):
                 assert np.array_equal(bg[k], grs[o][lv])
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("case,dims", [
+    ("parts_toy60_p1", [13, 8, 5]),
+    ("parts_toy60_p2", [602, 128, 41]),
+    ("parts_toy60_p4_hash", [33, 16, 7]),
+    ("parts_toy60_p4_hash", [300, 64, 64, 25]),      # 3 layers: only layer 0 changes order
+    ("parts_toy40_p3_empty", [20, 12, 4]),
+])
+def test_gcn_epoch_transform_first_vs_oracle(da, case, dims):
+    """Option gcn_transform_first: z0 = A(X W0), dW0 = X^T(A^T g0) -- every tensor the reference order also
+    produces (all but ah0) and the summed weight gradients against the same oracle epoch, P partitions."""
+    from helpers import oracle_gcn_epoch, rel_err
+    gs, parts = _golden_partitions(case)
+    V = int(gs[0]["globalVtxCnt"])
+    rng = np.random.default_rng(7)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)
+          for i in range(len(dims) - 1)]
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, transform_first=True)
+    assert ctxs[0].transform_first_active()
+    T, dW = oracle_gcn_epoch(gs, parts, X, labels, Ws, V)
+    L = len(dims) - 1
+    for r, c in enumerate(ctxs):
+        if gs[r]["localVtxCnt"] == 0:
+            continue
+        for l in range(L):
+            if l > 0:
+                assert rel_err(c.download(l, "ah"), T[r][f"ah{l}"]) < RTOL, (r, l, "ah")
+            if l < L - 1:
+                assert rel_err(c.download(l, "z"), T[r][f"z{l}"]) < RTOL, (r, l, "z")
+                assert rel_err(c.download(l, "h"), T[r][f"h{l}"]) < RTOL
+                assert rel_err(c.download(l, "aTg"), T[r][f"aTg{l}"]) < RTOL
+                assert rel_err(c.download(l, "g"), T[r][f"g{l}"]) < RTOL
+        assert rel_err(c.download(L - 1, "g"), T[r]["d"]) < RTOL
+    for l in range(L):
+        assert rel_err(dWs[l], dW[l]) < RTOL, ("dW", l)
+    for c in ctxs:
+        c.close()
+
+
+def test_transform_first_engine_epochs_match_reference_order(da):
+    """dory_engine_run in both orders: same weights after 3 epochs (within fp32 rounding), and the mode is
+    ignored when the first hidden layer is not narrower than the input."""
+    from helpers import rel_err
+    import partition_oracle as po
+    rng = np.random.default_rng(3)
+    V, E = 500, 6000
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    out = {}
+    for tf in (0, 1):
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, [96, 32, 6], V)
+        ctx.set_option("gcn_transform_first", tf)
+        ctx.graph_upload(g)
+        ctx.preallocate()
+        ctx.fill_uniform(0, "x", 3, -1.0, 1.0, g["localToGlobal"])
+        ctx.labels_upload(rng.integers(0, 6, V).astype(np.uint32) * 0 + (np.arange(V) % 6).astype(np.uint32))
+        ctx.weights_init_xavier()
+        ctx.adam_config(0.01)
+        assert ctx.transform_first_active() == bool(tf)
+        eng = da.NativeEngine(ctx)
+        eng.run(3)
+        out[tf] = [ctx.weight_get(l, "w") for l in range(2)] + [ctx.download(0, "h")]
+        eng.close()
+        ctx.close()
+    for a, b in zip(out[0], out[1]):
+        assert rel_err(a, b) < 1e-4
+    ctx = da.Context(0)
+    ctx.configure(da.GCN, [16, 32, 6], V)
+    ctx.set_option("gcn_transform_first", 1)
+    assert not ctx.transform_first_active()      # 16 -> 32: aggregating first is already the narrow side
+    ctx.close()
+    # partitions built with undirected = 1 carry the reference's ghost-degree quirk: csrVal != cscVal^T,
+    # dory_partition_upload marks them and the mode stays off
+    for und, want in ((0, True), (1, False)):
+        part = da.Partition.build(s.astype(np.uint32), d.astype(np.uint32), np.zeros(V, np.int32), 0, 1, undirected=und)
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, [96, 32, 6], V)
+        ctx.set_option("gcn_transform_first", 1)
+        part.upload(ctx)
+        assert ctx.transform_first_active() == want
+        ctx.close()
 
 
 def test_gcn_epoch_native_partition_and_plan(da):
