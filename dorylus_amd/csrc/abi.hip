@@ -221,6 +221,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
+    c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
     c->opt["gcn_transform_first"] = 0;   // GCN layer 0 as A(XW) instead of (AX)W when the input is wider than the output (see tf_active)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
@@ -475,6 +476,22 @@ int dory_preallocate(dory_ctx *c) {
     }
     c->adam.epochs = 1;
     HIPCK(c, hipStreamSynchronize(c->compute));
+    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_blocked"]) {
+        // the extension's forward sum gathers through the same source-blocked copy of the in-edges
+        uint32_t maxld = 0;
+        for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
+        if ((rc = ensure_blocked(c, true, blk_group_for(c, maxld)))) return rc;
+        if ((rc = ensure_blocked(c, false, blk_group_for(c, maxld)))) return rc;   // backward, source side
+        const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+        const size_t need = (size_t)nbmax * N * (maxld + 64) * sizeof(float);      // + per-(block,row,head) partials
+        if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
+            if (c->partial) (void)hipFree(c->partial);
+            c->partial = nullptr;
+            c->partial_bytes = 0;
+            HIPCK(c, hipMalloc((void **)&c->partial, need));
+            c->partial_bytes = need;
+        }
+    }
     if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn != DORY_GATMH) {   // K1b: regroup the edges now, not inside the first epoch
         uint32_t minld = 0xFFFFFFFFu;
         for (uint32_t l = 0; l < L; ++l) {
@@ -790,8 +807,15 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         if (dir == DORY_FORWARD) {
             {
                 Timed t(c, "spmm", c->compute);
-                HIPCK(c, launch_gatmh_forward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, z->d, el->d, er->d, o->d,
-                                              m->d, den->d, c->compute));
+                const bool blocked = c->opt["gatmh_blocked"] && c->blkIn_built && !c->blkIn_na && c->blkIn.nb > 0 &&
+                                     (D % 4 == 0 || K == 1) &&
+                                     (size_t)c->blkIn.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
+                if (blocked)
+                    HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->blkIn, z->d,
+                                                          el->d, er->d, o->d, m->d, den->d, c->partial, c->compute));
+                else
+                    HIPCK(c, launch_gatmh_forward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, z->d, el->d, er->d,
+                                                  o->d, m->d, den->d, c->compute));
             }
             Timed t(c, "loss", c->compute);
             if (!last) {
@@ -817,6 +841,21 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
         Timed t(c, "spmm", c->compute);
+        const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+        if (c->opt["gatmh_blocked"] && c->blkIn_built && c->blkOut_built && !c->blkIn_na && !c->blkOut_na && nbmax > 0 &&
+            gatmh_backward_blocked_ok(K, D, z->ld) &&
+            (size_t)nbmax * c->N * (z->ld + K) * sizeof(float) <= c->partial_bytes &&
+            c->scratch_bytes >= (size_t)c->N * K * 16 + 256 + (size_t)z->cols * sizeof(float)) {
+            float4 *st4 = reinterpret_cast<float4 *>(c->scratch);
+            const size_t st4_bytes = ((size_t)c->N * K * 16 + 255) & ~(size_t)255;
+            HIPCK(c, launch_gatmh_backward_blocked(c->N, K, D, z->ld, el->ld, c->blkIn, c->blkOut, z->d, el->d, er->d, m->d,
+                                                   den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d, tt->d,
+                                                   del->d, der->d, dz->d, c->partial, st4, c->compute));
+            HIPCK(c, launch_gatmh_dattn(c->N, K, D, z->ld, el->ld, z->d, del->d, der->d, c->wgrads[fl]["a_l"].d,
+                                        c->wgrads[fl]["a_r"].d, c->scratch + st4_bytes / sizeof(float),
+                                        c->scratch_bytes - st4_bytes, c->compute));
+            return DORY_OK;
+        }
         HIPCK(c, launch_gatmh_backward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->rowPtr, c->colIdx, z->d, el->d,
                                        er->d, m->d, den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d,
                                        tt->d, del->d, der->d, dz->d, c->wgrads[fl]["a_l"].d, c->wgrads[fl]["a_r"].d,

@@ -228,12 +228,27 @@ hipError_t launch_gatmh_scores(uint32_t N, uint32_t K, uint32_t D, const float *
 hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                 const uint32_t *rowidx, const float *z, const float *el, const float *er, float *o,
                                 float *m, float *den, hipStream_t s);
+// source-blocked forward (statistics pass, weighted sum over K1b's blocked adjacency, reduce + self edge)
+hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                        const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
+                                        const float *z, const float *el, const float *er, float *o, float *m,
+                                        float *den, float *partial /*nb x N x ld*/, hipStream_t s);
 hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                  const uint32_t *rowidx, const uint64_t *rowptr, const uint32_t *colidx,
                                  const float *z, const float *el, const float *er, const float *m, const float *den,
                                  const float *d_o, const float *a_l, const float *a_r, float *t, float *del,
                                  float *der, float *dz, float *da_l, float *da_r, float *scratch,
                                  size_t scratch_bytes, hipStream_t s);
+// source-blocked backward (needs both blocked adjacencies; see gatmh_backward_blocked_ok) and the a_l/a_r gradients
+bool gatmh_backward_blocked_ok(uint32_t K, uint32_t D, uint32_t ld);
+hipError_t launch_gatmh_backward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                         const BlockedAdj &Bin, const BlockedAdj &Bout, const float *z, const float *el,
+                                         const float *er, const float *m, const float *den, const float *d_o,
+                                         const float *a_l, const float *a_r, float *t, float *del, float *der, float *dz,
+                                         float *partial /*max(nb) x N x (ld + K) floats*/, float4 *st4, hipStream_t s);
+hipError_t launch_gatmh_dattn(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const float *z,
+                              const float *del, const float *der, float *da_l, float *da_r, float *scratch,
+                              size_t scratch_bytes, hipStream_t s);
 hipError_t launch_gatmh_elu(uint64_t rows, uint32_t cols, const float *o, uint32_t ldo, float *h, uint32_t ldh, hipStream_t s);
 hipError_t launch_gatmh_elu_bwd(uint64_t rows, uint32_t cols, const float *dh, uint32_t lddh, const float *o,
                                 uint32_t ldo, float *d_o, uint32_t lddo, hipStream_t s);

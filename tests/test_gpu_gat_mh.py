@@ -15,7 +15,8 @@ RTOL = 1e-4
     ([20, 128, 5], [4, 1], 180, 1300),       # 4 heads x 32
     ([12, 100, 6], [1, 1], 160, 1100),       # one head of 100 features: split over 4 lanes, last piece ragged
 ])
-def test_gat_mh_epoch_vs_oracle(dims, heads, V, E):
+@pytest.mark.parametrize("nb", [0, 8])    # 8: force the source-blocked forward on these L2-sized graphs
+def test_gat_mh_epoch_vs_oracle(dims, heads, V, E, nb):
     import dorylus_amd as da
     import gat_mh_oracle as go
     import partition_oracle as po
@@ -35,6 +36,7 @@ def test_gat_mh_epoch_vs_oracle(dims, heads, V, E):
     ctx = da.Context(0)
     ctx.configure(da.GATMH, dims, V)
     ctx.gatmh_heads(heads)
+    ctx.set_option("spmm_blk_nb", nb)
     ctx.graph_upload(g)
     ctx.preallocate()
     ctx.upload(0, "h", X)
