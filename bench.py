@@ -275,6 +275,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not gat and not args.emulate and args.workload == "reddit":
         cpu = cpu_baseline(ctx, g, args.cpu_rows)
 
+    # ---- the same epoch in the transform-first order of layer 0 (opt-in mode, reported beside the headline) ----
+    alt = None
+    if world == 1 and not gat and not tf_mode and not args.emulate and not args.opt:
+        ctx.set_option("gcn_transform_first", 1)
+        if ctx.transform_first_active():
+            ctx.timing_enable(False)
+            eng.run(max(1, args.warmup))
+            alt_ms = eng.run(args.steps)
+            alt = {"layer0_order": "transform-first A(XW) [opt-in: z0 = A(X W0), dW0 = X^T(A^T g0); not the reference order]",
+                   "ms_per_step": float(np.mean(alt_ms)), "epoch_ms_median": float(np.median(alt_ms)),
+                   "aggregations_per_epoch": "2 x CSC + 2 x CSR, all dims[1] wide"}
+        ctx.set_option("gcn_transform_first", 0)
+
     if gat or tf_mode or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
         roofline_gemm = None
@@ -299,6 +312,7 @@ def main():
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
+            "transform_first": alt,
             "cpu_baseline": cpu,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
             "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1),

@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--nbs", type=int, nargs="+", default=[0])
     ap.add_argument("--forms", type=int, nargs="+", default=[1])
     ap.add_argument("--window", type=int, default=0, help="draw sources from [0, window): L2-resident gather probe")
-    ap.add_argument("--opt", nargs="*", default=[], help="extra context options key=value (e.g. spmm_march_nacc=4)")
+    ap.add_argument("--opt", nargs="*", default=[], help="extra context options key=value (e.g. spmm_blk_force_split=1)")
     a = ap.parse_args()
     N = 232965
     E = int(114615892 * a.scale)
