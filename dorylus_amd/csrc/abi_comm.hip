@@ -1,0 +1,306 @@
+// abi_comm.hip -- C-ABI, part 3: ghost-vertex halo exchange (plan, RCCL all-to-all-v, pack / unpack for foreign
+// transports), weight-gradient all-reduce + Adam, and the epoch graph (hipGraph record / replay).
+#include "abi_internal.hpp"
+
+using namespace dory;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+int dory_halo_plan(dory_ctx *c, int dir, const uint32_t *send_counts, const uint32_t *send_lvids,
+                   const uint32_t *recv_counts, const uint32_t *recv_slots) {
+    CHECK_CTX(c);
+    if (!c->configured || !c->has_graph || (dir != 0 && dir != 1) || !send_counts || !recv_counts)
+        return fail(c, DORY_ERR_ARG, "halo_plan: configure + graph_upload first / bad args");
+    HaloPlan &p = c->plan[dir];
+    const uint32_t P = c->numNodes;
+    p.send_counts.assign(send_counts, send_counts + P);
+    p.recv_counts.assign(recv_counts, recv_counts + P);
+    p.send_off.assign(P + 1, 0);
+    p.recv_off.assign(P + 1, 0);
+    for (uint32_t i = 0; i < P; ++i) {
+        p.send_off[i + 1] = p.send_off[i] + p.send_counts[i];
+        p.recv_off[i + 1] = p.recv_off[i] + p.recv_counts[i];
+    }
+    p.send_total = p.send_off[P];
+    p.recv_total = p.recv_off[P];
+    const uint32_t G = dir == DORY_FORWARD ? c->Gsrc : c->Gdst;
+    if (p.send_counts[c->nodeId] || p.recv_counts[c->nodeId]) return fail(c, DORY_ERR_ARG, "halo_plan: self entry must be empty");
+    if (p.recv_total != G) return fail(c, DORY_ERR_ARG, "halo_plan: recv rows %u != ghost count %u", p.recv_total, G);
+    for (uint32_t i = 0; i < p.send_total; ++i)
+        if (send_lvids[i] >= c->N) return fail(c, DORY_ERR_ARG, "halo_plan: send lvid out of range");
+    std::vector<char> seen(G, 0);
+    for (uint32_t i = 0; i < p.recv_total; ++i) {
+        if (recv_slots[i] >= G || seen[recv_slots[i]]) return fail(c, DORY_ERR_ARG, "halo_plan: recv slots must be a permutation of the ghost slots");
+        seen[recv_slots[i]] = 1;
+    }
+    if (p.d_send_lvids) (void)hipFree(p.d_send_lvids);
+    if (p.d_recv_slots) (void)hipFree(p.d_recv_slots);
+    p.d_send_lvids = p.d_recv_slots = nullptr;
+    int rc;
+    if ((rc = upload_array(c, &p.d_send_lvids, send_lvids, p.send_total))) return rc;
+    if ((rc = upload_array(c, &p.d_recv_slots, recv_slots, p.recv_total))) return rc;
+    p.set = true;
+    return DORY_OK;
+}
+
+int dory_comm_unique_id(void *id128) {
+    if (!id128) return DORY_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return DORY_ERR_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return DORY_OK;
+}
+
+int dory_comm_init(dory_ctx *c, const void *id128, int rank, int nranks) {
+    CHECK_CTX(c);
+    if (!id128 || rank < 0 || rank >= nranks) return fail(c, DORY_ERR_ARG, "comm_init: bad arguments");
+    if (c->nccl) { ncclCommDestroy((ncclComm_t)c->nccl); c->nccl = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm;
+    NCCLCK(c, ncclCommInitRank(&comm, nranks, id, rank));
+    c->nccl = comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    return DORY_OK;
+}
+
+// resolve (layer, dir) -> source tensor, ghost tensor, width, as Engine::scatterGCN/GAT do
+static int halo_tensors(dory_ctx *c, uint32_t layer, int dir, Tensor **src, Tensor **ghost) {
+    if (c->gnn == DORY_GCN && layer == 0 && dir == DORY_BACKWARD && tf_active(c)) {
+        *src = find(c, 0, "g");      // transform-first: A^T g0 needs the ghost rows of g0
+        *ghost = find(c, 0, "bgg");
+    } else if (c->gnn == DORY_GCN) {
+        if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "halo: layer %u out of range", layer);
+        if (dir == DORY_FORWARD) { *src = find(c, layer - 1, "h"); *ghost = find(c, layer, "fg"); }   // gcn_ops.cpp:205-214
+        else { *src = find(c, layer, "grad"); *ghost = find(c, layer - 1, "bg"); }
+    } else {
+        if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "halo: layer %u out of range", layer);
+        if (dir == DORY_FORWARD) { *src = find(c, layer - 1, "z"); *ghost = find(c, layer - 1, "fg_z"); }  // gat_ops.cpp:277-287
+        else { *src = find(c, layer - 1, "grad"); *ghost = find(c, layer - 1, "bg_d"); }
+    }
+    if (!*src || !*ghost) return fail(c, DORY_ERR_ARG, "halo: tensors missing");
+    return DORY_OK;
+}
+
+int dory_halo_pack(dory_ctx *c, uint32_t layer, int dir, float *send_buf) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *src, *ghost;
+    int rc = halo_tensors(c, layer, dir, &src, &ghost);
+    if (rc) return rc;
+    HaloPlan &p = c->plan[dir];
+    if (!p.set) return fail(c, DORY_ERR_ARG, "halo_pack: no plan");
+    Timed t(c, "halo", c->compute);
+    HIPCK(c, launch_gather_rows(send_buf, src->d, src->ld, src->ld, p.d_send_lvids, p.send_total, c->compute));
+    return DORY_OK;
+}
+
+int dory_halo_unpack(dory_ctx *c, uint32_t layer, int dir, const float *recv_buf) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *src, *ghost;
+    int rc = halo_tensors(c, layer, dir, &src, &ghost);
+    if (rc) return rc;
+    HaloPlan &p = c->plan[dir];
+    if (!p.set) return fail(c, DORY_ERR_ARG, "halo_unpack: no plan");
+    Timed t(c, "halo", c->compute);
+    HIPCK(c, launch_scatter_rows(ghost->d, recv_buf, ghost->ld, ghost->ld, p.d_recv_slots, p.recv_total, c->compute));
+    return DORY_OK;
+}
+
+int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (c->numNodes == 1) return DORY_OK;  // no ghosts
+    if (c->gnn == DORY_GATMH) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only");
+    Tensor *src, *ghost;
+    int rc = halo_tensors(c, layer, dir, &src, &ghost);
+    if (rc) return rc;
+    HaloPlan &p = c->plan[dir];
+    if (!p.set) return fail(c, DORY_ERR_ARG, "halo_exchange: no plan");
+    if (!c->nccl) return fail(c, DORY_ERR_COMM, "halo_exchange: dory_comm_init not called");
+    if (c->nranks != (int)c->numNodes) return fail(c, DORY_ERR_COMM, "halo_exchange: communicator size != num_nodes");
+    const uint32_t w = src->ld;  // padded row width travels (keeps 16-B lanes)
+    const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
+    if (sb > c->send_cap) {
+        HIPCK(c, hipDeviceSynchronize());
+        if (c->send_buf) (void)hipFree(c->send_buf);
+        HIPCK(c, hipMalloc((void **)&c->send_buf, sb));
+        c->send_cap = sb;
+    }
+    if (rb > c->recv_cap) {
+        HIPCK(c, hipDeviceSynchronize());
+        if (c->recv_buf) (void)hipFree(c->recv_buf);
+        HIPCK(c, hipMalloc((void **)&c->recv_buf, rb));
+        c->recv_cap = rb;
+    }
+    // comm stream waits for the producer of `src` on the compute stream
+    HIPCK(c, hipEventRecord(c->ev_a, c->compute));
+    HIPCK(c, hipStreamWaitEvent(c->comm, c->ev_a, 0));
+    {
+        Timed t(c, "halo", c->comm);
+        HIPCK(c, launch_gather_rows(c->send_buf, src->d, src->ld, w, p.d_send_lvids, p.send_total, c->comm));
+        ncclComm_t comm = (ncclComm_t)c->nccl;
+        NCCLCK(c, ncclGroupStart());
+        for (uint32_t peer = 0; peer < c->numNodes; ++peer) {
+            if (peer == c->nodeId) continue;
+            if (p.send_counts[peer])
+                NCCLCK(c, ncclSend(c->send_buf + (size_t)p.send_off[peer] * w, (size_t)p.send_counts[peer] * w,
+                                   ncclFloat, (int)peer, comm, c->comm));
+            if (p.recv_counts[peer])
+                NCCLCK(c, ncclRecv(c->recv_buf + (size_t)p.recv_off[peer] * w, (size_t)p.recv_counts[peer] * w,
+                                   ncclFloat, (int)peer, comm, c->comm));
+        }
+        NCCLCK(c, ncclGroupEnd());
+        HIPCK(c, launch_scatter_rows(ghost->d, c->recv_buf, ghost->ld, w, p.d_recv_slots, p.recv_total, c->comm));
+    }
+    // consumers on the compute stream wait for the ghosts: at once, or (halo_overlap) when
+    // the first of them needs the ghost rows -- see wait_halo()
+    HIPCK(c, hipEventRecord(c->ev_b, c->comm));
+    if (c->opt["halo_overlap"]) c->halo_pending = true;
+    else HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int dory_adam_config(dory_ctx *c, float learning_rate) {
+    CHECK_CTX(c);
+    c->adam.lr = learning_rate;
+    c->adam.epochs = 1;
+    c->lr_table_left = 0;   // an epoch graph's step-size table is refilled on its next launch
+    return DORY_OK;
+}
+
+int dory_weight_update(dory_ctx *c, uint32_t layer) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (!c->prealloc || layer >= c->L) return fail(c, DORY_ERR_ARG, "weight_update: bad state or layer");
+    // AdamOptimizer::nextIteration (src/weight-server/AdamOptimizer.cpp:29-34)
+    const float b1p = (float)std::pow((double)0.9f, (double)c->adam.epochs);
+    const float b2p = (float)std::pow((double)0.999f, (double)c->adam.epochs);
+    const float lr_t = (float)(c->adam.lr * (std::sqrt((double)(1 - b2p))) / (1 - b1p));
+    for (auto &kv : c->weights[layer]) {
+        const std::string &name = kv.first;
+        // the reference only updates "w"; a_i updates are faked on the weight server
+        // (src/weight-server/weightserver.cpp:112-116) -- keep a_i fixed as it does.
+        if (name != "w" && c->gnn != DORY_GATMH) continue;   // the extension trains a_l / a_r too
+        Tensor &w = kv.second;
+        Tensor &g = c->wgrads[layer][name];
+        const uint64_t n = (uint64_t)w.rows * w.ld;
+        if (c->numNodes > 1) {
+            if (!c->nccl) return fail(c, DORY_ERR_COMM, "weight_update: dory_comm_init not called");
+            // sum of per-partition updates (WeightTensor::localUpdate/ghostUpdate,
+            // src/weight-server/weighttensor.cpp:131-166) as one RCCL all-reduce
+            Timed t(c, "allreduce", c->compute);
+            NCCLCK(c, ncclAllReduce(g.d, g.d, n, ncclFloat, ncclSum, (ncclComm_t)c->nccl, c->compute));
+        }
+        Timed t(c, "adam", c->compute);
+        if (c->capturing)   // replayed epochs: step size from the table dory_epoch_graph_launch fills
+            HIPCK(c, launch_adam_table(w.d, g.d, c->adam_m[layer][name].d, c->adam_v[layer][name].d, n, c->d_lr_table,
+                                       c->d_replay_idx, c->compute));
+        else
+            HIPCK(c, launch_adam(w.d, g.d, c->adam_m[layer][name].d, c->adam_v[layer][name].d, n, lr_t, c->compute));
+    }
+    if (layer == 0 && !c->capturing) {   // "if(layer == 0) nextIteration();" (AdamOptimizer.cpp:49-50)
+        c->adam.epochs += 1;
+        c->lr_table_left = 0;            // eager step: a recorded epoch's table no longer lines up
+    }
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Epoch graph: one epoch of C-ABI calls recorded into a hipGraph and replayed, so that a
+// launch-bound epoch (Cora-sized graphs: ~35 kernels of a few microseconds) costs one
+// graph launch.  No reference counterpart; single partition only (the exchange is not
+// recorded).  Everything an epoch allocates lazily must exist already: run one eager epoch
+// first.  Per-epoch host scalars do not survive recording, so Adam's step size comes from a
+// device table indexed by a replay counter that the graph's last node bumps.
+static float adam_lr_t(const dory_ctx *c, unsigned epochs) {   // AdamOptimizer::nextIteration, as dory_weight_update
+    const float b1p = (float)std::pow((double)0.9f, (double)epochs);
+    const float b2p = (float)std::pow((double)0.999f, (double)epochs);
+    return (float)(c->adam.lr * (std::sqrt((double)(1 - b2p))) / (1 - b1p));
+}
+
+static void epoch_graph_drop_locked(dory_ctx *c) {
+    if (c->capturing) {   // abandon a recording in progress
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(c->compute, &g);
+        if (g) (void)hipGraphDestroy(g);
+        c->capturing = false;
+    }
+    if (c->epoch_exec) (void)hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) (void)hipGraphDestroy(c->epoch_graph);
+    c->epoch_exec = nullptr;
+    c->epoch_graph = nullptr;
+    c->lr_table_left = 0;
+}
+
+int dory_epoch_graph_drop(dory_ctx *c) {
+    CHECK_CTX(c);
+    epoch_graph_drop_locked(c);
+    return DORY_OK;
+}
+
+int dory_epoch_graph_begin(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "epoch_graph_begin: preallocate first");
+    if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "epoch graph: single partition only (the halo exchange is not recorded)");
+    if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch_graph_begin: already recording");
+    epoch_graph_drop_locked(c);
+    if (!c->d_replay_idx) HIPCK(c, hipMalloc((void **)&c->d_replay_idx, 256));
+    if (!c->d_lr_table) {
+        c->lr_table_cap = 1024;
+        HIPCK(c, hipMalloc((void **)&c->d_lr_table, c->lr_table_cap * sizeof(float)));
+    }
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    HIPCK(c, hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return DORY_OK;
+}
+
+int dory_epoch_graph_end(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->capturing) return fail(c, DORY_ERR_ARG, "epoch_graph_end: not recording");
+    hipError_t e = launch_bump_counter(c->d_replay_idx, c->compute);
+    hipGraph_t g = nullptr;
+    hipError_t e2 = hipStreamEndCapture(c->compute, &g);
+    c->capturing = false;
+    if (e != hipSuccess || e2 != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        return fail(c, DORY_ERR_HIP, "epoch_graph_end: recording failed (%s)", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    c->epoch_graph = g;
+    e = hipGraphInstantiate(&c->epoch_exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        c->epoch_exec = nullptr;
+        epoch_graph_drop_locked(c);
+        return fail(c, DORY_ERR_HIP, "epoch_graph_end: hipGraphInstantiate failed (%s)", hipGetErrorString(e));
+    }
+    return DORY_OK;
+}
+
+int dory_epoch_graph_launch(dory_ctx *c, uint32_t epochs) {
+    CHECK_CTX(c);
+    if (!c->epoch_exec) return fail(c, DORY_ERR_ARG, "epoch_graph_launch: no recorded epoch");
+    for (uint32_t i = 0; i < epochs; ++i) {
+        if (c->lr_table_left == 0) {
+            // step sizes of the next replays, a pure function of the iteration count: filled well
+            // ahead so that the host copy + counter reset happen once per lr_table_cap epochs
+            HIPCK(c, hipStreamSynchronize(c->compute));   // previous replays have read the old table
+            c->lr_table_host.resize(c->lr_table_cap);
+            for (uint32_t k = 0; k < c->lr_table_cap; ++k) c->lr_table_host[k] = adam_lr_t(c, c->adam.epochs + k);
+            HIPCK(c, hipMemcpy(c->d_lr_table, c->lr_table_host.data(), c->lr_table_cap * sizeof(float), hipMemcpyHostToDevice));
+            HIPCK(c, hipMemset(c->d_replay_idx, 0, sizeof(uint32_t)));
+            c->lr_table_left = c->lr_table_cap;
+        }
+        HIPCK(c, hipGraphLaunch(c->epoch_exec, c->compute));
+        c->lr_table_left -= 1;
+        c->adam.epochs += 1;
+    }
+    return DORY_OK;
+}
+
+}  // extern "C"

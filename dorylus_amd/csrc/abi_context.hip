@@ -1,0 +1,648 @@
+// abi_context.hip -- C-ABI, part 1 (include/dorylus_hip.h): context, device tensor table, graph / tensor /
+// weight uploads, options and timing.  The stage dispatch is in abi_stages.hip, the exchange and the weight update
+// in abi_comm.hip.  Reference paths are relative to src/graph-server/ unless they start with src/.
+#include "abi_internal.hpp"
+
+namespace dory {
+
+static std::string g_create_err;
+
+int fail(dory_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+void drain_timing(dory_ctx *c) {
+    for (auto &p : c->pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->times[p.fam].total_ms += ms;
+            c->times[p.fam].launches += 1;
+        }
+        c->ev_pool.push_back({p.a, p.b});
+    }
+    c->pending.clear();
+}
+
+int alloc_tensor(dory_ctx *c, Tensor &t, uint64_t rows, uint32_t cols) {
+    t.rows = rows;
+    t.cols = cols;
+    t.ld = pad_ld(cols);
+    t.owned = true;
+    t.d = nullptr;
+    size_t b = t.bytes();
+    if (b == 0) b = 256;  // keep a valid pointer for empty ghosts
+    HIPCK(c, hipMalloc((void **)&t.d, b));
+    HIPCK(c, hipMemsetAsync(t.d, 0, b, c->compute));
+    return DORY_OK;
+}
+
+Tensor *find(dory_ctx *c, uint32_t layer, const char *name) {
+    if (layer >= c->tensors.size()) return nullptr;
+    auto it = c->tensors[layer].find(name);
+    return it == c->tensors[layer].end() ? nullptr : &it->second;
+}
+Tensor *findw(std::vector<std::map<std::string, Tensor>> &tab, uint32_t layer, const char *name) {
+    if (layer >= tab.size()) return nullptr;
+    auto it = tab[layer].find(name);
+    return it == tab[layer].end() ? nullptr : &it->second;
+}
+
+void free_table(std::vector<std::map<std::string, Tensor>> &tab) {
+    for (auto &m : tab)
+        for (auto &kv : m)
+            if (kv.second.owned && kv.second.d) (void)hipFree(kv.second.d);
+    tab.clear();
+}
+
+int ensure_scratch(dory_ctx *c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return DORY_OK;
+    if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: scratch would have to grow while recording (run one eager epoch first)");
+    if (c->scratch) {
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        (void)hipFree(c->scratch);
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+    }
+    HIPCK(c, hipMalloc((void **)&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return DORY_OK;
+}
+
+// longest-row-first schedule for skewed degree distributions
+std::vector<uint32_t> degree_order(const uint64_t *ptr, uint32_t N) {
+    std::vector<uint32_t> o(N);
+    std::iota(o.begin(), o.end(), 0u);
+    std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) {
+        return (ptr[a + 1] - ptr[a]) > (ptr[b + 1] - ptr[b]);
+    });
+    return o;
+}
+
+int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const Tensor &A,
+         const Tensor &B, Tensor &C, Tensor *C2) {
+    GemmArgs g{};
+    g.ta = ta; g.tb = tb; g.M = M; g.N = N; g.K = K;
+    g.A = A.d; g.lda = A.ld; g.B = B.d; g.ldb = B.ld; g.C = C.d; g.ldc = C.ld;
+    g.epilogue = C2 ? EPI_TANH : EPI_NONE;
+    if (C2) { g.C2 = C2->d; g.ldc2 = C2->ld; }
+    size_t need = gemm_scratch_bytes(M, N, K);
+    if (need > ((size_t)256 << 20)) need = (size_t)256 << 20;
+    int rc = ensure_scratch(c, need);
+    if (rc) return rc;
+    Timed t(c, "gemm", c->compute);
+    HIPCK(c, launch_gemm(g, c->scratch, c->scratch_bytes, c->compute));
+    return DORY_OK;
+}
+// Ghost rows of the last halo exchange land on the comm stream; with "halo_overlap" the
+// compute stream is only made to wait for them (event ev_b) by the first consumer.
+int wait_halo(dory_ctx *c) {
+    if (c->halo_pending) {
+        HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+        c->halo_pending = false;
+    }
+    return DORY_OK;
+}
+
+// Transform-first order for GCN layer 0 (opt-in, no reference counterpart): A(XW0) gathers d1-wide rows
+// instead of the d0-wide rows of (AX)W0 -- 128 instead of 602 floats per edge on Reddit.  The weight gradient
+// follows as X^T(A^T g0): one more d1-wide SpMM on the out-edges.  "ah"@0 is not produced in this mode.
+bool tf_active(dory_ctx *c) {
+    return c->gnn == DORY_GCN && c->L >= 2 && c->dims[0] > c->dims[1] && c->opt["gcn_transform_first"] != 0 &&
+           c->opt["adjacency_values_asymmetric"] == 0;
+}
+
+}  // namespace dory
+
+using namespace dory;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+int dory_create(int device, dory_ctx **out) {
+    if (!out) return DORY_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(nullptr, DORY_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, DORY_ERR_ARG, "device %d out of range (%d)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(nullptr, DORY_ERR_HIP, "hipGetDeviceProperties failed");
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, DORY_ERR_NODEVICE, "device %d is %s; kernels are built for gfx950 only", device,
+                    prop.gcnArchName);
+    dory_ctx *c = new dory_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&c->d_stat, 2 * sizeof(float)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, DORY_ERR_HIP, "stream/event creation failed");
+    }
+    (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
+    c->own_compute = c->own_comm = true;
+    c->opt["spmm_variant"] = 1;      // 1: K1b source-blocked L2-resident gather where it applies, 0: K1 only
+    c->opt["spmm_slab"] = 0;
+    c->opt["spmm_order"] = 1;
+    c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
+    c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
+    c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
+    c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
+    c->opt["gcn_transform_first"] = 0;   // GCN layer 0 as A(XW) instead of (AX)W when the input is wider than the output (see tf_active)
+    c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
+    c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
+    *out = c;
+    return DORY_OK;
+}
+
+static void free_graph(dory_ctx *c) {
+    void *ps[] = {c->colPtr, c->rowPtr, c->rowIdx, c->colIdx, c->cscVal, c->csrVal, c->norm, c->orderIn, c->orderOut};
+    for (void *p : ps)
+        if (p) (void)hipFree(p);
+    c->colPtr = c->rowPtr = nullptr;
+    c->rowIdx = c->colIdx = nullptr;
+    c->cscVal = c->csrVal = c->norm = nullptr;
+    c->orderIn = c->orderOut = nullptr;
+    free_blocked(&c->blkIn);
+    free_blocked(&c->blkOut);
+    c->blkIn_built = c->blkOut_built = false;
+    c->blkIn_na = c->blkOut_na = false;
+    c->has_graph = false;
+}
+
+int dory_destroy(dory_ctx *c) {
+    if (!c) return DORY_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    drain_timing(c);
+    for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
+    free_table(c->tensors);
+    free_table(c->weights);
+    free_table(c->wgrads);
+    free_table(c->adam_m);
+    free_table(c->adam_v);
+    free_graph(c);
+    for (int d = 0; d < 2; ++d) {
+        if (c->plan[d].d_send_lvids) (void)hipFree(c->plan[d].d_send_lvids);
+        if (c->plan[d].d_recv_slots) (void)hipFree(c->plan[d].d_recv_slots);
+    }
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->partial) (void)hipFree(c->partial);
+    if (c->epoch_exec) (void)hipGraphExecDestroy(c->epoch_exec);
+    if (c->epoch_graph) (void)hipGraphDestroy(c->epoch_graph);
+    if (c->d_lr_table) (void)hipFree(c->d_lr_table);
+    if (c->d_replay_idx) (void)hipFree(c->d_replay_idx);
+    if (c->send_buf) (void)hipFree(c->send_buf);
+    if (c->recv_buf) (void)hipFree(c->recv_buf);
+    if (c->d_stat) (void)hipFree(c->d_stat);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->own_compute && c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->own_comm && c->comm) (void)hipStreamDestroy(c->comm);
+    delete c;
+    return DORY_OK;
+}
+
+const char *dory_last_error(dory_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int dory_set_streams(dory_ctx *c, void *compute_stream, void *comm_stream) {
+    CHECK_CTX(c);
+    HIPCK(c, hipDeviceSynchronize());
+    if (compute_stream) {
+        if (c->own_compute) (void)hipStreamDestroy(c->compute);
+        c->compute = (hipStream_t)compute_stream;
+        c->own_compute = false;
+    }
+    if (comm_stream) {
+        if (c->own_comm) (void)hipStreamDestroy(c->comm);
+        c->comm = (hipStream_t)comm_stream;
+        c->own_comm = false;
+    }
+    return DORY_OK;
+}
+
+int dory_sync(dory_ctx *c) {
+    CHECK_CTX(c);
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    HIPCK(c, hipStreamSynchronize(c->comm));
+    c->halo_pending = false;   // everything has landed
+    return DORY_OK;
+}
+
+int dory_configure(dory_ctx *c, int gnn_type, uint32_t num_layers, const uint32_t *dims,
+                   uint32_t global_vtx_cnt, uint32_t node_id, uint32_t num_nodes) {
+    CHECK_CTX(c);
+    if (!dims || num_layers == 0 || (gnn_type != DORY_GCN && gnn_type != DORY_GAT && gnn_type != DORY_GATMH) || num_nodes == 0 ||
+        node_id >= num_nodes)
+        return fail(c, DORY_ERR_ARG, "dory_configure: bad arguments");
+    for (uint32_t i = 0; i <= num_layers; ++i)
+        if (dims[i] == 0) return fail(c, DORY_ERR_ARG, "dory_configure: zero layer width");
+    c->gnn = gnn_type;
+    c->L = num_layers;
+    c->dims.assign(dims, dims + num_layers + 1);
+    c->globalV = global_vtx_cnt;
+    c->nodeId = node_id;
+    c->numNodes = num_nodes;
+    c->heads.assign(num_layers, 8);   // multi-head GAT extension defaults: 8 hidden heads, 1 output head
+    c->heads[num_layers - 1] = 1;
+    c->configured = true;
+    return DORY_OK;
+}
+
+int dory_gatmh_heads(dory_ctx *c, const uint32_t *heads) {
+    CHECK_CTX(c);
+    if (!c->configured || c->gnn != DORY_GATMH || !heads) return fail(c, DORY_ERR_ARG, "gatmh_heads: configure with DORY_GATMH first");
+    for (uint32_t l = 0; l < c->L; ++l)
+        if (heads[l] == 0 || heads[l] > 64) return fail(c, DORY_ERR_ARG, "gatmh_heads: bad head count");
+    c->heads.assign(heads, heads + c->L);
+    return DORY_OK;
+}
+
+int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uint64_t nnz_in,
+                      const uint64_t *column_ptrs, const uint32_t *row_idxs, const float *csc_values,
+                      uint64_t nnz_out, const uint64_t *row_ptrs, const uint32_t *column_idxs,
+                      const float *csr_values, const float *vtx_norms) {
+    CHECK_CTX(c);
+    if (!column_ptrs || !row_ptrs || (N && !vtx_norms) || (nnz_in && (!row_idxs || !csc_values)) ||
+        (nnz_out && (!column_idxs || !csr_values)))
+        return fail(c, DORY_ERR_ARG, "dory_graph_upload: null array");
+    if (column_ptrs[0] != 0 || column_ptrs[N] != nnz_in || row_ptrs[0] != 0 || row_ptrs[N] != nnz_out)
+        return fail(c, DORY_ERR_ARG, "dory_graph_upload: pointer arrays do not match nnz");
+    for (uint32_t v = 0; v < N; ++v)
+        if (column_ptrs[v] > column_ptrs[v + 1] || row_ptrs[v] > row_ptrs[v + 1])
+            return fail(c, DORY_ERR_ARG, "dory_graph_upload: pointer array not monotone at %u", v);
+    for (uint64_t e = 0; e < nnz_in; ++e)
+        if (row_idxs[e] >= (uint64_t)N + Gsrc) return fail(c, DORY_ERR_ARG, "row index %u out of range at %llu", row_idxs[e], (unsigned long long)e);
+    for (uint64_t e = 0; e < nnz_out; ++e)
+        if (column_idxs[e] >= (uint64_t)N + Gdst) return fail(c, DORY_ERR_ARG, "column index %u out of range at %llu", column_idxs[e], (unsigned long long)e);
+    HIPCK(c, hipDeviceSynchronize());
+    free_graph(c);
+    c->N = N; c->Gsrc = Gsrc; c->Gdst = Gdst; c->nnz_in = nnz_in; c->nnz_out = nnz_out;
+    int rc;
+    if ((rc = upload_array(c, &c->colPtr, column_ptrs, (uint64_t)N + 1))) return rc;
+    if ((rc = upload_array(c, &c->rowIdx, row_idxs, nnz_in))) return rc;
+    if ((rc = upload_array(c, &c->cscVal, csc_values, nnz_in))) return rc;
+    if ((rc = upload_array(c, &c->rowPtr, row_ptrs, (uint64_t)N + 1))) return rc;
+    if ((rc = upload_array(c, &c->colIdx, column_idxs, nnz_out))) return rc;
+    if ((rc = upload_array(c, &c->csrVal, csr_values, nnz_out))) return rc;
+    if ((rc = upload_array(c, &c->norm, vtx_norms, (uint64_t)N))) return rc;
+    auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
+    if ((rc = upload_array(c, &c->orderIn, oi.data(), (uint64_t)N))) return rc;
+    if ((rc = upload_array(c, &c->orderOut, oo.data(), (uint64_t)N))) return rc;
+    c->has_graph = true;
+    return DORY_OK;
+}
+
+int dory_preallocate(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->configured || !c->has_graph) return fail(c, DORY_ERR_ARG, "dory_preallocate: configure and graph_upload first");
+    HIPCK(c, hipDeviceSynchronize());
+    free_table(c->tensors); free_table(c->weights); free_table(c->wgrads); free_table(c->adam_m); free_table(c->adam_v);
+    const uint32_t L = c->L, N = c->N;
+    auto &d = c->dims;
+    c->tensors.assign(L + 1, {});
+    c->weights.assign(L, {}); c->wgrads.assign(L, {}); c->adam_m.assign(L, {}); c->adam_v.assign(L, {});
+    int rc = 0;
+    auto mk = [&](uint32_t layer, const char *name, uint64_t rows, uint32_t cols) {
+        if (rc) return;
+        rc = alloc_tensor(c, c->tensors[layer][name], rows, cols);
+    };
+    if (c->gnn == DORY_GCN) {  // Engine::preallocateGCN (engine/ops/gcn_ops.cpp:27-93)
+        mk(0, "x", N, d[0]);
+        mk(0, "fg", c->Gsrc, d[0]);
+        mk(L - 1, "lab", N, d[L]);
+        for (uint32_t l = 0; l < L; ++l) {
+            mk(l, "ah", N, d[l]);
+            mk(l, "z", N, d[l + 1]);            // reference keeps z only for l < L-1; last-layer logits are a temporary there
+            if (l < L - 1) {
+                mk(l, "h", N, d[l + 1]);
+                mk(l + 1, "fg", c->Gsrc, d[l + 1]);
+            }
+            mk(l, "g", N, d[l + 1]);            // interGrad / d_output temporaries of CPU_comm.cpp:121,143
+        }
+        for (uint32_t l = L - 1; l > 0; --l) {
+            mk(l, "grad", N, d[l]);
+            mk(l - 1, "bg", c->Gdst, d[l]);
+            mk(l - 1, "aTg", N, d[l]);
+        }
+        if (L >= 2 && d[0] > d[1]) {   // transform-first order of layer 0 (option gcn_transform_first)
+            mk(0, "xw", N, d[1]);          // X W0
+            mk(0, "fgxw", c->Gsrc, d[1]);  // the same for the layer-0 ghost rows
+            mk(0, "u", N, d[1]);           // A^T g0
+            mk(0, "bgg", c->Gdst, d[1]);   // ghost rows of g0 (backward exchange at layer 0)
+        }
+    } else if (c->gnn == DORY_GATMH) {  // extension (no reference counterpart): see dory_gatmh_heads
+        if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only in this version");
+        mk(0, "h", N, d[0]);
+        mk(L - 1, "lab", N, d[L]);
+        mk(L - 1, "logits", N, d[L]);
+        mk(L - 1, "grad", N, d[L]);
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t K = c->heads[l];
+            const bool last = l == L - 1;
+            const uint32_t zw = last ? d[l + 1] * K : d[l + 1];
+            const uint32_t D = zw / K;
+            if (zw % K || zw > 256 || (K > 1 && ((D & (D - 1)) || D > 64)))
+                return fail(c, DORY_ERR_ARG, "multi-head GAT: layer %u width %u does not split into %u heads (D power of two <= 64, K*D <= 256)", l, zw, K);
+            mk(l, "z", N, zw);
+            mk(l, "o", N, zw);
+            mk(l, "do", N, zw);
+            mk(l, "dz", N, zw);
+            for (const char *nm : {"el", "er", "m", "den", "t", "del", "der"}) mk(l, nm, N, K);
+            if (!last) mk(l + 1, "h", N, d[l + 1]);
+            if (l > 0) mk(l, "dh", N, d[l]);
+        }
+    } else {  // Engine::preallocateGAT (engine/ops/gat_ops.cpp:27-115)
+        mk(0, "h", N, d[0]);
+        mk(L - 1, "lab", N, d[L]);
+        for (uint32_t l = 0; l < L; ++l) {
+            mk(l, "z", N, d[l + 1]);
+            mk(l, "az", c->nnz_in, 1);
+            mk(l, "fg_z", c->Gsrc, d[l + 1]);
+            Tensor A;  // "A" aliases forwardAdj.values (gat_ops.cpp:61-64)
+            A.rows = c->nnz_in; A.cols = 1; A.ld = 1; A.d = c->cscVal; A.owned = false;
+            c->tensors[l]["A"] = A;
+            mk(l, "ah", N, d[l + 1]);
+            if (l < L - 1) mk(l + 1, "h", N, d[l + 1]);
+            mk(l, "grad", N, d[l + 1]);
+            mk(l, "dA", c->nnz_in, 1);
+            mk(l, "aTg", N, d[l + 1]);
+            mk(l, "bg_d", c->Gdst, d[l + 1]);
+        }
+        mk(0, "cw", N, 1);  // column weights for the a_i gradient (K5)
+        for (uint32_t l = 0; l < L; ++l) {
+            mk(l, "arow", N, 1);   // per-destination value of "A"  (all edges of a column are equal)
+            mk(l, "drow", N, 1);   // per-destination value of "dA"
+        }
+        c->gat_arow_valid.assign(L, 0);
+        c->gat_drow_valid.assign(L, 0);
+    }
+    if (rc) return rc;
+    for (uint32_t l = 0; l < L; ++l) {
+        if (c->gnn == DORY_GATMH) {
+            const uint32_t zw = l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1];
+            for (auto *tab : {&c->weights, &c->wgrads, &c->adam_m, &c->adam_v}) {
+                if ((rc = alloc_tensor(c, (*tab)[l]["w"], d[l], zw))) return rc;
+                if ((rc = alloc_tensor(c, (*tab)[l]["a_l"], zw, 1))) return rc;
+                if ((rc = alloc_tensor(c, (*tab)[l]["a_r"], zw, 1))) return rc;
+            }
+            continue;
+        }
+        if ((rc = alloc_tensor(c, c->weights[l]["w"], d[l], d[l + 1]))) return rc;
+        if ((rc = alloc_tensor(c, c->wgrads[l]["w"], d[l], d[l + 1]))) return rc;
+        if ((rc = alloc_tensor(c, c->adam_m[l]["w"], d[l], d[l + 1]))) return rc;
+        if ((rc = alloc_tensor(c, c->adam_v[l]["w"], d[l], d[l + 1]))) return rc;
+        if (c->gnn == DORY_GAT) {
+            if ((rc = alloc_tensor(c, c->weights[l]["a_i"], d[l + 1], 1))) return rc;
+            if ((rc = alloc_tensor(c, c->wgrads[l]["a_i"], d[l + 1], 1))) return rc;
+            if ((rc = alloc_tensor(c, c->adam_m[l]["a_i"], d[l + 1], 1))) return rc;
+            if ((rc = alloc_tensor(c, c->adam_v[l]["a_i"], d[l + 1], 1))) return rc;
+        }
+    }
+    c->adam.epochs = 1;
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_blocked"]) {
+        // the extension's forward sum gathers through the same source-blocked copy of the in-edges
+        uint32_t maxld = 0;
+        for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
+        if ((rc = ensure_blocked(c, true, blk_group_for(c, maxld)))) return rc;
+        if ((rc = ensure_blocked(c, false, blk_group_for(c, maxld)))) return rc;   // backward, source side
+        const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+        const size_t need = (size_t)nbmax * N * (maxld + 64) * sizeof(float);      // + per-(block,row,head) partials
+        if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
+            if (c->partial) (void)hipFree(c->partial);
+            c->partial = nullptr;
+            c->partial_bytes = 0;
+            HIPCK(c, hipMalloc((void **)&c->partial, need));
+            c->partial_bytes = need;
+        }
+    }
+    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn != DORY_GATMH) {   // K1b: regroup the edges now, not inside the first epoch
+        uint32_t minld = 0xFFFFFFFFu;
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t w = c->gnn == DORY_GCN ? (l == 0 ? d[0] : d[l]) : d[l + 1];
+            minld = std::min(minld, pad_ld(w));
+        }
+        uint32_t maxld = 0;
+        for (uint32_t l = 0; l <= L; ++l) maxld = std::max(maxld, pad_ld(d[l]));
+        const int group = blk_group_for(c, maxld);   // block size for the widest rows (most of the traffic)
+        if (minld >= 32) {
+            if ((rc = ensure_blocked(c, true, group))) return rc;
+            if ((rc = ensure_blocked(c, false, group))) return rc;
+            // the partial-sum buffer too, so that no allocation happens inside an epoch
+            const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+            const size_t need = (size_t)nbmax * N * maxld * sizeof(float);
+            if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
+                if (c->partial) (void)hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
+        }
+    }
+    c->prealloc = true;
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int dory_tensor_info(dory_ctx *c, uint32_t layer, const char *name, uint64_t *rows, uint32_t *cols,
+                     uint32_t *ld, void **device_ptr) {
+    CHECK_CTX(c);
+    Tensor *t = name ? find(c, layer, name) : nullptr;
+    if (!t) return fail(c, DORY_ERR_ARG, "no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (rows) *rows = t->rows;
+    if (cols) *cols = t->cols;
+    if (ld) *ld = t->ld;
+    if (device_ptr) *device_ptr = t->d;
+    return DORY_OK;
+}
+
+static int upload_dense(dory_ctx *c, Tensor &t, const float *host) {
+    if (t.rows == 0 || t.cols == 0) return DORY_OK;
+    if (t.ld == t.cols) {
+        HIPCK(c, hipMemcpyAsync(t.d, host, t.bytes(), hipMemcpyHostToDevice, c->compute));
+    } else {
+        float *stage = nullptr;
+        const size_t b = (size_t)t.rows * t.cols * sizeof(float);
+        HIPCK(c, hipMalloc((void **)&stage, b));
+        HIPCK(c, hipMemcpyAsync(stage, host, b, hipMemcpyHostToDevice, c->compute));
+        HIPCK(c, launch_pad_copy(t.d, t.ld, stage, t.cols, t.rows, t.cols, c->compute));
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        (void)hipFree(stage);
+    }
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    return DORY_OK;
+}
+
+static int download_dense(dory_ctx *c, const Tensor &t, float *host) {
+    if (t.rows == 0 || t.cols == 0) return DORY_OK;
+    HIPCK(c, hipStreamSynchronize(c->comm));
+    if (t.ld == t.cols) {
+        HIPCK(c, hipMemcpyAsync(host, t.d, t.bytes(), hipMemcpyDeviceToHost, c->compute));
+    } else {
+        HIPCK(c, hipMemcpy2DAsync(host, (size_t)t.cols * sizeof(float), t.d, (size_t)t.ld * sizeof(float),
+                                  (size_t)t.cols * sizeof(float), t.rows, hipMemcpyDeviceToHost, c->compute));
+    }
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    return DORY_OK;
+}
+
+int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const float *host) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *t = name ? find(c, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_upload: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
+    if (!strcmp(name, "dA") && layer < c->gat_drow_valid.size()) c->gat_drow_valid[layer] = 0;
+    return upload_dense(c, *t, host);
+}
+
+int dory_tensor_download(dory_ctx *c, uint32_t layer, const char *name, float *host) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *t = name ? find(c, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_download: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    return download_dense(c, *t, host);
+}
+
+int dory_tensor_fill_uniform(dory_ctx *c, uint32_t layer, const char *name, uint64_t seed, float lo,
+                             float hi, const uint32_t *global_row_ids) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *t = name ? find(c, layer, name) : nullptr;
+    if (!t) return fail(c, DORY_ERR_ARG, "tensor_fill: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    uint32_t *ids = nullptr;
+    if (global_row_ids && t->rows) {
+        int rc = upload_array(c, &ids, global_row_ids, t->rows);
+        if (rc) return rc;
+    }
+    HIPCK(c, launch_fill_uniform_ids(t->d, t->rows, t->cols, t->ld, ids, seed, lo, hi, c->compute));
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    if (ids) (void)hipFree(ids);
+    return DORY_OK;
+}
+
+int dory_labels_upload(dory_ctx *c, const uint32_t *labels) {
+    CHECK_CTX(c);
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "labels_upload: preallocate first");
+    Tensor *t = find(c, c->L - 1, "lab");
+    if (!t || (!labels && t->rows)) return fail(c, DORY_ERR_ARG, "labels_upload: bad arguments");
+    for (uint64_t i = 0; i < t->rows; ++i)
+        if (labels[i] >= t->cols) return fail(c, DORY_ERR_ARG, "label %u at row %llu exceeds %u classes", labels[i], (unsigned long long)i, t->cols);
+    uint32_t *dl = nullptr;
+    int rc = upload_array(c, &dl, labels, t->rows);
+    if (rc) return rc;
+    HIPCK(c, launch_onehot(t->d, t->rows, t->cols, t->ld, dl, c->compute));
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    (void)hipFree(dl);
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int dory_weight_set(dory_ctx *c, uint32_t layer, const char *name, const float *host) {
+    CHECK_CTX(c);
+    Tensor *t = name ? findw(c->weights, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "weight_set: no weight '%s' at layer %u", name ? name : "(null)", layer);
+    return upload_dense(c, *t, host);
+}
+int dory_weight_get(dory_ctx *c, uint32_t layer, const char *name, float *host) {
+    CHECK_CTX(c);
+    Tensor *t = name ? findw(c->weights, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "weight_get: no weight '%s' at layer %u", name ? name : "(null)", layer);
+    return download_dense(c, *t, host);
+}
+int dory_weight_grad_get(dory_ctx *c, uint32_t layer, const char *name, float *host) {
+    CHECK_CTX(c);
+    Tensor *t = name ? findw(c->wgrads, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "weight_grad_get: no gradient '%s' at layer %u", name ? name : "(null)", layer);
+    return download_dense(c, *t, host);
+}
+
+int dory_weights_init_xavier(dory_ctx *c) {
+    CHECK_CTX(c);
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "weights_init: preallocate first");
+    for (uint32_t l = 0; l < c->L; ++l) {
+        // WeightServer::xavierInitializer (src/weight-server/weightserver.cpp:567-585):
+        // every tensor restarts the engine at seed 8888.
+        for (auto &kv : c->weights[l]) {
+            Tensor &t = kv.second;
+            const uint32_t d1 = (uint32_t)t.rows, d2 = t.cols;
+            std::vector<float> w((size_t)d1 * d2);
+            std::default_random_engine dre(8888);
+            std::uniform_real_distribution<float> dist(-1, 1);
+            for (auto &x : w) x = dist(dre);
+            const float nf = std::sqrt(6.0 / (float(d1 + d2)));
+            for (auto &x : w) x *= nf;
+            int rc = upload_dense(c, t, w.data());
+            if (rc) return rc;
+        }
+    }
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int dory_ctx_describe(dory_ctx *c, int *gnn_type, uint32_t *num_layers, uint32_t *node_id, uint32_t *num_nodes,
+                      uint32_t *local_vtx_cnt) {
+    CHECK_CTX(c);
+    if (!c->configured || !c->has_graph) return fail(c, DORY_ERR_ARG, "ctx_describe: configure and graph_upload first");
+    if (gnn_type) *gnn_type = c->gnn;
+    if (num_layers) *num_layers = c->L;
+    if (node_id) *node_id = c->nodeId;
+    if (num_nodes) *num_nodes = c->numNodes;
+    if (local_vtx_cnt) *local_vtx_cnt = c->N;
+    return DORY_OK;
+}
+
+int dory_timing_enable(dory_ctx *c, int on) {
+    CHECK_CTX(c);
+    drain_timing(c);
+    c->timing = on != 0;
+    return DORY_OK;
+}
+int dory_timing_get(dory_ctx *c, const char *family, double *total_ms, uint64_t *launches) {
+    CHECK_CTX(c);
+    if (!family) return DORY_ERR_ARG;
+    drain_timing(c);
+    auto it = c->times.find(family);
+    if (total_ms) *total_ms = it == c->times.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == c->times.end() ? 0 : it->second.launches;
+    return DORY_OK;
+}
+int dory_timing_reset(dory_ctx *c) {
+    CHECK_CTX(c);
+    drain_timing(c);
+    c->times.clear();
+    return DORY_OK;
+}
+int dory_transform_first_active(dory_ctx *c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    return c->configured && tf_active(c) ? 1 : 0;
+}
+
+int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
+    CHECK_CTX(c);
+    if (!key || !value || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
+    *value = c->opt[key];
+    return DORY_OK;
+}
+
+int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
+    CHECK_CTX(c);
+    if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
+    c->opt[key] = value;
+    return DORY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,411 @@
+// abi_stages.hip -- C-ABI, part 2: the stage dispatch that replaces the reference's Engine::aggregate* bodies and
+// ResourceComm::NNCompute (aggregate, apply_vertex, apply_edge, predict, validation statistics).
+#include "abi_internal.hpp"
+
+namespace dory {
+// ---------------------------------------------------------------------------------------
+// K1b bookkeeping: (re)build the source-blocked copy of one adjacency for `group` lanes/row
+int ensure_blocked(dory_ctx *c, bool csc, int group) {
+    BlockedAdj &B = csc ? c->blkIn : c->blkOut;
+    bool &built = csc ? c->blkIn_built : c->blkOut_built;
+    const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
+    // the block structure serves every slab width; only an explicit block count forces a rebuild
+    if (c->capturing && (!built || (want_nb && B.nb != (want_nb + 7) / 8 * 8)) && !(csc ? c->blkIn_na : c->blkOut_na))
+        return fail(c, DORY_ERR_ARG, "epoch graph: blocked adjacency would have to be (re)built while recording");
+    if (built && want_nb && B.nb != (want_nb + 7) / 8 * 8) {
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        free_blocked(&B);
+        built = false;
+    }
+    if (!built) {
+        const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
+        // K1b pays nb partial rows per output row: only worth it (and only affordable: the
+        // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
+        // hundred L2 windows at most.  Larger partitions keep K1.
+        const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u);
+        // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
+        // K1 then gathers from L2 without partial sums or a second kernel
+        const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20);
+        if (tiny || nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
+            (csc ? c->blkIn_na : c->blkOut_na) = true;
+            return DORY_OK;
+        }
+        HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
+                               c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute));
+        B.row_bytes = (uint32_t)group * 16u;
+        built = true;
+    }
+    return DORY_OK;
+}
+
+int blk_group_for(dory_ctx *c, uint32_t ld) {
+    int group = (int)c->opt["spmm_blk_group"];
+    if (group != 8 && group != 16 && group != 32) group = 32;
+    if (ld < 128 && group == 32) group = 16;   // narrow tensors: one 256-B slab
+    return group;
+}
+
+// One aggregation.  Edge weights come from `val` (any per-edge array, K1), or -- when
+// `val` is the adjacency's own static array -- from the source-blocked copy (K1b), or are
+// 1 with a per-destination factor `row_scale` (K1b, unit mode; the reference GAT's edge
+// scores depend on the destination only, CPU_comm.cpp:299-319).
+static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &xl, Tensor *xg, Tensor &out,
+                uint32_t F, int accumulate, const float *row_scale = nullptr) {
+    if (xl.ld != out.ld || (xg && xg->rows && xg->ld != xl.ld) || xl.cols != F)
+        return fail(c, DORY_ERR_ARG, "spmm: tensor shapes disagree (F=%u ld %u/%u)", F, xl.ld, out.ld);
+    SpmmArgs a{};
+    a.N = c->N; a.F = F; a.ld = xl.ld;
+    a.ptr = csc ? c->colPtr : c->rowPtr;
+    a.idx = csc ? c->rowIdx : c->colIdx;
+    a.val = val;
+    a.self_scale = c->norm;
+    a.self_mode = self_mode;
+    a.xl = xl.d; a.xg = xg ? xg->d : nullptr; a.out = out.d;
+    a.accumulate = accumulate;
+    a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
+    const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal
+    if (c->opt["spmm_variant"] == 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+        const int group = blk_group_for(c, a.ld);
+        int rc = ensure_blocked(c, csc, group);
+        if (rc) return rc;
+        BlockedAdj &B = csc ? c->blkIn : c->blkOut;
+        const size_t need = blocked_partial_bytes(a, B);
+        if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
+            if (need > c->partial_bytes) {
+                if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: partial buffer would have to grow while recording");
+                HIPCK(c, hipStreamSynchronize(c->compute));
+                if (c->partial) (void)hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
+            Timed t(c, "spmm", c->compute);
+            // source blocks that contain local rows only do not depend on the exchange in
+            // flight: they run first, the ghost blocks after the comm stream's event
+            const uint32_t nb_local = std::min(B.nb, c->N / B.SB);
+            const bool split = (c->halo_pending || c->opt["spmm_blk_force_split"]) && nb_local > 0 && nb_local < B.nb;
+            if (split) {
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, nb_local, c->compute));
+                if ((rc = wait_halo(c))) return rc;
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, nb_local, B.nb, c->compute));
+            } else {
+                if ((rc = wait_halo(c))) return rc;
+                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, B.nb, c->compute));
+            }
+            HIPCK(c, launch_spmm_blocked_reduce(a, B, c->partial, row_scale, c->compute));
+            return DORY_OK;
+        }
+    }
+    if (!val) return fail(c, DORY_ERR_ARG, "spmm: no edge values");
+    {
+        int rc = wait_halo(c);
+        if (rc) return rc;
+    }
+    Timed t(c, "spmm", c->compute);
+    HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+    return DORY_OK;
+}
+
+
+}  // namespace dory
+
+using namespace dory;
+
+extern "C" {
+
+int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
+    CHECK_CTX(c);
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "aggregate: preallocate first");
+    if (c->gnn == DORY_GCN) {  // Engine::aggregateGCN (gcn_ops.cpp:130-191)
+        if (dir == DORY_FORWARD) {
+            if (layer >= c->L) return fail(c, DORY_ERR_ARG, "aggregate: layer %u out of range", layer);
+            Tensor *in = layer == 0 ? find(c, 0, "x") : find(c, layer - 1, "h");
+            NEED(fg, layer, "fg");
+            NEED(ah, layer, "ah");
+            if (!in) return fail(c, DORY_ERR_ARG, "aggregate: input tensor missing");
+            if (layer == 0 && tf_active(c)) {   // z0 = A (X W0): transform the local and the ghost rows, then gather d1-wide
+                NEED(xw, 0, "xw"); NEED(fgxw, 0, "fgxw"); NEED(z, 0, "z");
+                Tensor &W = c->weights[0]["w"];
+                int rc = gemm(c, 0, 0, c->N, c->dims[1], c->dims[0], *in, W, *xw);
+                if (!rc && c->Gsrc) rc = gemm(c, 0, 0, c->Gsrc, c->dims[1], c->dims[0], *fg, W, *fgxw);
+                if (rc) return rc;
+                return spmm(c, true, c->cscVal, 1, *xw, fgxw, *z, c->dims[1], 0);
+            }
+            return spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+        }
+        if (layer == 0 && tf_active(c)) {   // dW0 = X^T (A^T g0)   (ghost rows of g0: halo exchange (0, backward))
+            NEED(g, 0, "g"); NEED(bgg, 0, "bgg"); NEED(u, 0, "u"); NEED(x, 0, "x");
+            int rc = spmm(c, false, c->csrVal, 1, *g, bgg, *u, c->dims[1], 0);
+            if (rc) return rc;
+            return gemm(c, 1, 0, c->dims[0], c->dims[1], c->N, *x, *u, c->wgrads[0]["w"]);
+        }
+        if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "aggregate backward: layer %u out of range", layer);
+        NEED(grad, layer, "grad");
+        NEED(bg, layer - 1, "bg");
+        NEED(aTg, layer - 1, "aTg");
+        return spmm(c, false, c->csrVal, 1, *grad, bg, *aTg, c->dims[layer], 0);
+    }
+    // Engine::aggregateGAT (gat_ops.cpp:173-243): tensors live at layer-1
+    if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "aggregate GAT: layer %u out of range", layer);
+    const uint32_t fl = layer - 1;
+    if (c->gnn == DORY_GATMH) {  // extension: edge softmax + weighted sum, and its backward
+        const uint32_t K = c->heads[fl];
+        const bool last = fl == c->L - 1;
+        NEED(z, fl, "z"); NEED(el, fl, "el"); NEED(er, fl, "er"); NEED(m, fl, "m"); NEED(den, fl, "den"); NEED(o, fl, "o");
+        const uint32_t D = z->cols / K;
+        if (dir == DORY_FORWARD) {
+            {
+                Timed t(c, "spmm", c->compute);
+                const bool blocked = c->opt["gatmh_blocked"] && c->blkIn_built && !c->blkIn_na && c->blkIn.nb > 0 &&
+                                     (D % 4 == 0 || K == 1) &&
+                                     (size_t)c->blkIn.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
+                if (blocked)
+                    HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->blkIn, z->d,
+                                                          el->d, er->d, o->d, m->d, den->d, c->partial, c->compute));
+                else
+                    HIPCK(c, launch_gatmh_forward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, z->d, el->d, er->d,
+                                                  o->d, m->d, den->d, c->compute));
+            }
+            Timed t(c, "loss", c->compute);
+            if (!last) {
+                NEED(hn, fl + 1, "h");
+                HIPCK(c, launch_gatmh_elu(c->N, o->cols, o->d, o->ld, hn->d, hn->ld, c->compute));
+            } else {
+                NEED(lg, fl, "logits");
+                HIPCK(c, launch_gatmh_head_mean(c->N, K, lg->cols, o->d, o->ld, lg->d, lg->ld, c->compute));
+            }
+            return DORY_OK;
+        }
+        NEED(dO, fl, "do"); NEED(dz, fl, "dz"); NEED(tt, fl, "t"); NEED(del, fl, "del"); NEED(der, fl, "der");
+        {
+            Timed t(c, "loss", c->compute);
+            if (last) {
+                NEED(gr, fl, "grad");
+                HIPCK(c, launch_gatmh_head_expand(c->N, K, gr->cols, gr->d, gr->ld, dO->d, dO->ld, c->compute));
+            } else {
+                NEED(dh, fl + 1, "dh");
+                HIPCK(c, launch_gatmh_elu_bwd(c->N, o->cols, dh->d, dh->ld, o->d, o->ld, dO->d, dO->ld, c->compute));
+            }
+        }
+        int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
+        if (rc) return rc;
+        Timed t(c, "spmm", c->compute);
+        const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+        if (c->opt["gatmh_blocked"] && c->blkIn_built && c->blkOut_built && !c->blkIn_na && !c->blkOut_na && nbmax > 0 &&
+            gatmh_backward_blocked_ok(K, D, z->ld) &&
+            (size_t)nbmax * c->N * (z->ld + K) * sizeof(float) <= c->partial_bytes &&
+            c->scratch_bytes >= (size_t)c->N * K * 16 + 256 + (size_t)z->cols * sizeof(float)) {
+            float4 *st4 = reinterpret_cast<float4 *>(c->scratch);
+            const size_t st4_bytes = ((size_t)c->N * K * 16 + 255) & ~(size_t)255;
+            HIPCK(c, launch_gatmh_backward_blocked(c->N, K, D, z->ld, el->ld, c->blkIn, c->blkOut, z->d, el->d, er->d, m->d,
+                                                   den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d, tt->d,
+                                                   del->d, der->d, dz->d, c->partial, st4, c->compute));
+            HIPCK(c, launch_gatmh_dattn(c->N, K, D, z->ld, el->ld, z->d, del->d, der->d, c->wgrads[fl]["a_l"].d,
+                                        c->wgrads[fl]["a_r"].d, c->scratch + st4_bytes / sizeof(float),
+                                        c->scratch_bytes - st4_bytes, c->compute));
+            return DORY_OK;
+        }
+        HIPCK(c, launch_gatmh_backward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->rowPtr, c->colIdx, z->d, el->d,
+                                       er->d, m->d, den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d,
+                                       tt->d, del->d, der->d, dz->d, c->wgrads[fl]["a_l"].d, c->wgrads[fl]["a_r"].d,
+                                       c->scratch, c->scratch_bytes, c->compute));
+        return DORY_OK;
+    }
+    NEED(z, fl, "z");
+    NEED(fgz, fl, "fg_z");
+    // dory_apply_edge leaves, next to the per-edge tensors "A" / "dA", the one value all
+    // edges of a destination share; while that is current the SpMM gathers unweighted
+    // (K1b) and scales per row.  A caller that overwrote "A"/"dA" gets the general K1 path.
+    if (dir == DORY_FORWARD) {
+        NEED(ah, fl, "ah");
+        Tensor *arow = find(c, fl, "arow");
+        const bool fast = arow && fl < c->gat_arow_valid.size() && c->gat_arow_valid[fl];
+        return spmm(c, true, c->cscVal, 2, *z, fgz, *ah, c->dims[layer], 0, fast ? arow->d : nullptr);
+    }
+    NEED(grad, fl, "grad");
+    NEED(bgd, fl, "bg_d");
+    NEED(dA, fl, "dA");
+    NEED(aTg, fl, "aTg");
+    // fresh two-term sum (the CUDA path's semantics, gat_ops.cpp:155-163): A^T.dP then += dA.Z
+    int rc = spmm(c, false, c->csrVal, 0, *grad, bgd, *aTg, c->dims[layer], 0);
+    if (rc) return rc;
+    Tensor *drow = find(c, fl, "drow");
+    const bool fast = drow && fl < c->gat_drow_valid.size() && c->gat_drow_valid[fl];
+    return spmm(c, true, dA->d, 0, *z, fgz, *aTg, c->dims[layer], 1, fast ? drow->d : nullptr);
+}
+
+int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (!c->prealloc) return fail(c, DORY_ERR_ARG, "apply_vertex: preallocate first");
+    if (layer >= c->L) return fail(c, DORY_ERR_ARG, "apply_vertex: layer %u out of range", layer);
+    const uint32_t N = c->N, Fin = c->dims[layer], Fout = c->dims[layer + 1];
+    Tensor &W = c->weights[layer]["w"];
+    Tensor &dW = c->wgrads[layer]["w"];
+    int rc;
+    if (c->gnn == DORY_GCN) {
+        NEED(ah, layer, "ah");
+        NEED(z, layer, "z");
+        NEED(g, layer, "g");
+        if (dir == DORY_FORWARD) {
+            if (layer != c->L - 1) {  // vtxNNForwardGCN hidden (CPU_comm.cpp:98-107)
+                NEED(h, layer, "h");
+                if (layer == 0 && tf_active(c)) {   // z0 came out of dory_aggregate already
+                    Timed t(c, "loss", c->compute);
+                    HIPCK(c, launch_tanh_forward(N, Fout, z->d, z->ld, h->d, h->ld, c->compute));
+                    return DORY_OK;
+                }
+                return gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z, h);
+            }
+            // last layer (CPU_comm.cpp:108-133)
+            NEED(lab, layer, "lab");
+            if ((rc = gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z))) return rc;
+            const uint32_t stt = (uint32_t)(N * 0.66);            // TRAIN_PORTION
+            const uint32_t vend = stt + (uint32_t)(N * 0.1);      // VAL_PORTION
+            c->val_rows = vend - stt;
+            const float denom = (float)(c->globalV * 0.66);
+            if ((rc = ensure_scratch(c, (size_t)(2 * ((vend - stt + 255) / 256) + 64) * sizeof(float)))) return rc;
+            {
+                Timed t(c, "loss", c->compute);
+                // maskout copies (N - stt) floats starting at dense offset stt*cols (CPU_comm.cpp:464-471)
+                HIPCK(c, launch_softmax_xent(N, Fout, z->d, z->ld, lab->d, lab->ld, g->d, g->ld, denom, stt,
+                                             vend, (uint64_t)stt * Fout, (uint64_t)(N - stt), c->d_stat,
+                                             c->scratch, c->compute));
+            }
+            if (layer > 0) {  // interGrad = d_output * W^T -> "grad"
+                NEED(grad, layer, "grad");
+                if ((rc = gemm(c, 0, 1, N, Fin, Fout, *g, W, *grad))) return rc;
+            }
+            return gemm(c, 1, 0, Fin, Fout, N, *ah, *g, dW);  // ah^T * d_output
+        }
+        // vtxNNBackwardGCN (CPU_comm.cpp:137-159)
+        NEED(aTg, layer, "aTg");
+        {
+            Timed t(c, "loss", c->compute);
+            HIPCK(c, launch_tanh_backward(N, Fout, aTg->d, aTg->ld, z->d, z->ld, g->d, g->ld, c->compute));
+        }
+        if (layer == 0 && tf_active(c)) return DORY_OK;   // dW0 follows in dory_aggregate(0, backward)
+        if ((rc = gemm(c, 1, 0, Fin, Fout, N, *ah, *g, dW))) return rc;
+        if (layer != 0) {
+            NEED(grad, layer, "grad");
+            return gemm(c, 0, 1, N, Fin, Fout, *g, W, *grad);
+        }
+        return DORY_OK;
+    }
+    if (c->gnn == DORY_GATMH) {  // extension: z = h*W ; backward dW = h^T dz, dh = dz W^T
+        NEED(hh, layer, "h");
+        NEED(z, layer, "z");
+        const uint32_t zw = z->cols;
+        if (dir == DORY_FORWARD) return gemm(c, 0, 0, N, zw, Fin, *hh, W, *z);
+        NEED(dz, layer, "dz");
+        if ((rc = gemm(c, 1, 0, Fin, zw, N, *hh, *dz, dW))) return rc;
+        if (layer != 0) {
+            NEED(dh, layer, "dh");
+            return gemm(c, 0, 1, N, Fin, zw, *dz, W, *dh);
+        }
+        return DORY_OK;
+    }
+    // GAT
+    Tensor *feats = layer == 0 ? find(c, 0, "h") : find(c, layer - 1, "ah");
+    if (!feats) return fail(c, DORY_ERR_ARG, "apply_vertex GAT: input missing");
+    if (dir == DORY_FORWARD) {  // vtxNNForwardGAT (CPU_comm.cpp:161-169)
+        NEED(z, layer, "z");
+        return gemm(c, 0, 0, N, Fout, Fin, *feats, W, *z);
+    }
+    // vtxNNBackwardGAT (CPU_comm.cpp:171-188)
+    NEED(aTg, layer, "aTg");
+    if ((rc = gemm(c, 1, 0, Fin, Fout, N, *feats, *aTg, dW))) return rc;
+    if (layer != 0) {
+        NEED(grad, layer - 1, "grad");
+        return gemm(c, 0, 1, N, Fin, Fout, *aTg, W, *grad);
+    }
+    return DORY_OK;
+}
+
+int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (!c->prealloc || c->gnn == DORY_GCN) {
+        if (c->prealloc && c->gnn == DORY_GCN) return DORY_OK;  // applyEdgeGCN is a no-op (gcn_ops.cpp:364-366)
+        return fail(c, DORY_ERR_ARG, "apply_edge: preallocate first");
+    }
+    if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "apply_edge: layer %u out of range", layer);
+    if (c->gnn == DORY_GATMH) {  // extension: attention scores per vertex and head; backward lives in aggregate
+        if (dir != DORY_FORWARD) return DORY_OK;
+        const uint32_t l0 = layer - 1, K = c->heads[l0];
+        NEED(z, l0, "z"); NEED(el, l0, "el"); NEED(er, l0, "er");
+        Timed t(c, "edge", c->compute);
+        HIPCK(c, launch_gatmh_scores(c->N, K, z->cols / K, z->d, z->ld, c->weights[l0]["a_l"].d, c->weights[l0]["a_r"].d,
+                                     el->d, er->d, el->ld, c->compute));
+        return DORY_OK;
+    }
+    const uint32_t fl = layer - 1;  // "layer--; // YIFAN: fix this" (CPU_comm.cpp:33)
+    const uint32_t F = c->dims[fl + 1];
+    Tensor &a = c->weights[fl]["a_i"];
+    NEED(z, fl, "z");
+    NEED(az, fl, "az");
+    if (dir == DORY_FORWARD) {  // edgNNForwardGAT (CPU_comm.cpp:190-203)
+        NEED(arow, fl, "arow");
+        Timed t(c, "edge", c->compute);
+        HIPCK(c, launch_edge_forward_gat(c->N, F, c->colPtr, z->d, z->ld, a.d, az->d, c->cscVal, arow->d, c->compute));
+        for (auto &f : c->gat_arow_valid) f = 0;   // "A" now holds this layer's scores only
+        c->gat_arow_valid[fl] = 1;
+        return DORY_OK;
+    }
+    // edgNNBackwardGAT (CPU_comm.cpp:205-242)
+    NEED(grad, fl, "grad");
+    NEED(dA, fl, "dA");
+    NEED(cw, 0, "cw");
+    NEED(drow, fl, "drow");
+    Tensor &da = c->wgrads[fl]["a_i"];
+    int rc = ensure_scratch(c, (size_t)(1024 * (size_t)F + F + c->N + 64) * sizeof(float));
+    if (rc) return rc;
+    float *r = c->scratch;            // F
+    float *y = c->scratch + ((F + 63) & ~63u);   // N
+    float *partial = y + ((c->N + 63) & ~63u);
+    const size_t pbytes = c->scratch_bytes - (size_t)(partial - c->scratch) * sizeof(float);
+    Timed t(c, "edge", c->compute);
+    HIPCK(c, launch_edge_backward_gat(c->N, F, c->colPtr, grad->d, grad->ld, az->d, a.d, dA->d, cw->d, drow->d, c->compute));
+    c->gat_drow_valid[fl] = 1;
+    // r = grad^T cw ; da = z^T (z r)   [= (z^T z) r^T, CPU_comm.cpp:232-236, without the F x F matrix]
+    HIPCK(c, launch_colsum_w(c->N, F, grad->d, grad->ld, cw->d, partial, pbytes, r, c->compute));
+    HIPCK(c, launch_rowdot(c->N, F, z->d, z->ld, r, y, c->compute));
+    HIPCK(c, launch_colsum_w(c->N, F, z->d, z->ld, y, partial, pbytes, da.d, c->compute));
+    return DORY_OK;
+}
+
+int dory_predict_gat(dory_ctx *c, uint32_t layer) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (!c->prealloc || c->gnn == DORY_GCN || layer == 0 || layer > c->L)
+        return fail(c, DORY_ERR_ARG, "predict_gat: bad state or layer");
+    const uint32_t fl = layer - 1;
+    if (c->gnn == DORY_GATMH) {
+        NEED(lg, fl, "logits"); NEED(lab, fl, "lab"); NEED(gr, fl, "grad");
+        Timed t(c, "loss", c->compute);
+        HIPCK(c, launch_softmax_sub(c->N, lg->cols, lg->d, lg->ld, lab->d, lab->ld, gr->d, gr->ld, c->compute));
+        return DORY_OK;
+    }
+    // Engine::predictGAT (gat_ops.cpp:246-265).  The reference reads the edge tensor
+    // "az" where it means the aggregated "ah" (SURVEY.md 0-6); we use "ah".
+    NEED(ah, fl, "ah");
+    NEED(lab, fl, "lab");
+    NEED(grad, fl, "grad");
+    Timed t(c, "loss", c->compute);
+    HIPCK(c, launch_softmax_sub(c->N, c->dims[layer], ah->d, ah->ld, lab->d, lab->ld, grad->d, grad->ld, c->compute));
+    return DORY_OK;
+}
+
+int dory_train_stat(dory_ctx *c, float *acc_sum, float *loss_sum, uint32_t *val_rows) {
+    CHECK_CTX(c);
+    float h[2] = {0, 0};
+    HIPCK(c, hipMemcpyAsync(h, c->d_stat, sizeof(h), hipMemcpyDeviceToHost, c->compute));
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    if (acc_sum) *acc_sum = h[0];
+    if (loss_sum) *loss_sum = h[1];
+    if (val_rows) *val_rows = c->val_rows;
+    return DORY_OK;
+}
+
+}  // extern "C"

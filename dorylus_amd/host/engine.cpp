@@ -227,7 +227,7 @@ struct dory_engine {
     bool recorded = false;   // the ctx holds a recorded epoch
 };
 
-// the engine needs a few facts the ctx already knows; they are exported by abi.hip
+// the engine needs a few facts the ctx already knows; they are exported by csrc/abi_context.hip
 extern "C" int dory_ctx_describe(dory_ctx *ctx, int *gnn, uint32_t *num_layers, uint32_t *node_id,
                                  uint32_t *num_nodes, uint32_t *local_vtx_cnt);
 

@@ -51,7 +51,7 @@ def _worker(rank, world, port, seed, ret):
             assert [int(allc[q][rank]) for q in range(world)] == [len(x) for x in recv_slots]
             send = [torch.from_numpy(np.ascontiguousarray(local[np.asarray(l, np.int64)])) for l in send_lists]
             recv = [torch.empty((len(s), F), dtype=torch.float32) for s in recv_slots]
-            # grouped point-to-point, the shape of the ncclSend/ncclRecv group in abi.hip
+            # grouped point-to-point, the shape of the ncclSend/ncclRecv group in csrc/abi_comm.hip
             reqs = []
             for q in range(world):
                 if q == rank:
