@@ -14,14 +14,9 @@
 // Backward uses the identity  der = sum a*da*l' - t * sum a*l'  (t = sum a*da) so the
 // destination side needs a single sweep over the in-edges; the source side (CSR) gathers
 // dO, er, m, den, t of each destination and produces del and the alpha-weighted dZ.
-#include "ctx.hpp"
+#include "gat_mh.hpp"
 
 namespace dory {
-
-constexpr float GATMH_SLOPE = 0.2f;
-constexpr int GATMH_MAXC = 4;   // K*D <= 256 (kernels are instantiated for 1, 2 or 4 chunks of 64 floats)
-
-__device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : GATMH_SLOPE * x; }
 
 // sum over the D lanes of a head group (D power of two <= 64), result in every lane of the group
 __device__ __forceinline__ float head_sum(float v, int D) {
@@ -46,13 +41,6 @@ __global__ void gatmh_scores_kernel(uint32_t N, uint32_t K, uint32_t D, const fl
     er[(size_t)v * ldk + k] = sr;
 }
 
-static bool gatmh_shape_ok(uint32_t K, uint32_t D);
-
-struct GatMhArgs {
-    uint32_t N, K, D, ld /*of z, o, do, dz*/, ldk /*of el, er, m, den, t, del, der*/;
-    const uint64_t *ptr;   // CSC (forward / dst pass) or CSR (src pass)
-    const uint32_t *idx;
-};
 
 // Forward: online softmax statistics, then alpha-weighted aggregation (self edge last).
 template <int NC>
@@ -138,175 +126,6 @@ __global__ __launch_bounds__(256) void gatmh_forward_kernel(GatMhArgs a, const f
         const uint32_t f = lane + 64 * c;
         if (f < KD) o[(size_t)v * a.ld + f] = acc[c];
     }
-}
-
-// ---- forward, source-blocked (K1b's idea applied to the attention-weighted sum) ---------------------------
-// The row-wise kernel above gathers Z rows from all over the graph: every gather misses L2.  Here the softmax
-// statistics come first (they only need el: N x K floats, L2-resident as a whole), then the weighted sum runs
-// over K1b's source-blocked adjacency -- workgroup id -> XCD id & 7, each XCD walks one 5 MB window of Z rows at a
-// time, alpha is recomputed per edge from el[src], er/m/den[dst] -- and a last kernel adds the partial rows and
-// the self edge.  Same mapping as spmm_blocked_kernel (spmm.hip): GROUP lanes x float4 = one slab of a row.
-__global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const float *el, const float *er, float *m_out,
-                                                          float *den_out) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= a.N) return;
-    uint32_t KP = 1;
-    while (KP < a.K) KP <<= 1;
-    const uint32_t EPC = 64 / KP;
-    const uint32_t k1 = lane % KP, j1 = lane / KP;
-    const bool kok = k1 < a.K;
-    const float er_v = kok ? er[(size_t)v * a.ldk + k1] : 0.f;
-    const uint64_t e_beg = a.ptr[v], e_end = a.ptr[v + 1];   // edge e_end stands for the self edge
-    float m = -INFINITY, den = 0.f;
-    for (uint64_t e0 = e_beg; e0 <= e_end; e0 += EPC) {
-        const uint64_t e = e0 + j1;
-        if (e <= e_end && kok) {
-            const uint32_t u = e < e_end ? a.idx[e] : v;
-            const float s = lrelu02(el[(size_t)u * a.ldk + k1] + er_v);
-            const float mn = fmaxf(m, s);
-            den = den * __expf(m - mn) + __expf(s - mn);
-            m = mn;
-        }
-    }
-    for (uint32_t off = KP; off < 64; off <<= 1) {
-        const float m2 = __shfl_xor(m, off, 64), d2 = __shfl_xor(den, off, 64);
-        const float mn = fmaxf(m, m2);
-        const float f1 = m == -INFINITY ? 0.f : __expf(m - mn), f2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
-        den = den * f1 + d2 * f2;
-        m = mn;
-    }
-    if (j1 == 0 && kok) {
-        m_out[(size_t)v * a.ldk + k1] = m;
-        den_out[(size_t)v * a.ldk + k1] = den;
-    }
-}
-
-constexpr int GATMH_BLK_ROWS = 64;   // destination rows per workgroup (as K1b)
-
-template <int GROUP>
-__global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
-                                                                    const float *el, const float *er,
-                                                                    const float *m_in, const float *den_in,
-                                                                    float *partial, uint32_t tiles, uint32_t rounds) {
-    constexpr int RPW = 64 / GROUP;
-    constexpr int BLK_ITER = GATMH_BLK_ROWS / (4 * RPW);
-    const uint32_t id = blockIdx.x;
-    const uint32_t xcd = id & 7u;
-    uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
-    q /= tiles;
-    const uint32_t round = q % rounds;
-    const uint32_t slab = q / rounds;
-    const uint32_t b = round * 8u + xcd;
-    if (b >= B.nb) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane % GROUP, gi = lane / GROUP;
-    const uint32_t nchunk = a.ld >> 2;
-    const uint32_t col = slab * GROUP + li;
-    const bool col_ok = col * 4 < a.K * a.D;
-    const uint32_t ccol = col_ok ? col : 0;
-    const uint32_t k = min((ccol * 4) / a.D, a.K - 1);          // one head per float4 (D % 4 == 0, or a single head)
-    const float4 *z4 = reinterpret_cast<const float4 *>(z);
-    float4 *p4 = reinterpret_cast<float4 *>(partial) + (size_t)b * a.N * nchunk;
-    const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
-    const uint64_t base = B.bbase[b];
-#pragma unroll 1
-    for (int it = 0; it < BLK_ITER; ++it) {
-        const uint32_t v = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
-        const bool row_ok = v < a.N;
-        const uint32_t vv = row_ok ? v : 0;
-        uint64_t e = row_ok ? base + boff[v] : 0;
-        const uint64_t end = row_ok ? base + boff[v + 1] : 0;
-        const float er_v = er[(size_t)vv * a.ldk + k], m_v = m_in[(size_t)vv * a.ldk + k];
-        const float idn = 1.f / den_in[(size_t)vv * a.ldk + k];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        while (e < end) {
-            const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
-            uint32_t my_idx = 0;
-            if (li < n) my_idx = __builtin_nontemporal_load(B.bidx + e + li);
-            int j = 0;
-            for (; j + 4 <= n; j += 4) {
-                float4 x[4];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t s = (uint32_t)__shfl((int)my_idx, j + u, GROUP);
-                    x[u] = z4[(size_t)s * nchunk + ccol];
-                    w[u] = el[(size_t)s * a.ldk + k];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float al = __expf(lrelu02(w[u] + er_v) - m_v) * idn;
-                    acc.x = fmaf(al, x[u].x, acc.x); acc.y = fmaf(al, x[u].y, acc.y);
-                    acc.z = fmaf(al, x[u].z, acc.z); acc.w = fmaf(al, x[u].w, acc.w);
-                }
-            }
-            for (; j < n; ++j) {
-                const uint32_t s = (uint32_t)__shfl((int)my_idx, j, GROUP);
-                const float4 x = z4[(size_t)s * nchunk + ccol];
-                const float al = __expf(lrelu02(el[(size_t)s * a.ldk + k] + er_v) - m_v) * idn;
-                acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
-                acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
-            }
-            e += n;
-        }
-        if (row_ok && col_ok) p4[(size_t)v * nchunk + col] = acc;
-    }
-}
-
-// o[v,:] = sum_b partial[b][v,:] + alpha_self * z[v,:]
-__global__ __launch_bounds__(256) void gatmh_forward_reduce_kernel(GatMhArgs a, uint32_t nb, const float *partial,
-                                                                   const float *z, const float *el, const float *er,
-                                                                   const float *m_in, const float *den_in, float *o) {
-    const uint32_t nchunk = a.ld >> 2;
-    const size_t n = (size_t)a.N * nchunk;
-    const float4 *p4 = reinterpret_cast<const float4 *>(partial);
-    const float4 *z4 = reinterpret_cast<const float4 *>(z);
-    float4 *o4 = reinterpret_cast<float4 *>(o);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t v = (uint32_t)(i / nchunk), col = (uint32_t)(i % nchunk);
-        if (col * 4 >= a.K * a.D) continue;
-        const uint32_t k = min((col * 4) / a.D, a.K - 1);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t b = 0; b < nb; ++b) {
-            const float4 p = p4[(size_t)b * n + i];
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
-        const size_t vk = (size_t)v * a.ldk + k;
-        const float al = __expf(lrelu02(el[vk] + er[vk]) - m_in[vk]) / den_in[vk];   // the self edge
-        const float4 x = z4[i];
-        acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
-        acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
-        o4[i] = acc;
-    }
-}
-
-hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
-                                        const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
-                                        const float *z, const float *el, const float *er, float *o, float *m,
-                                        float *den, float *partial, hipStream_t s) {
-    if (N == 0) return hipSuccess;
-    if (!gatmh_shape_ok(K, D) || ((D & 3) && K != 1) || (ld & 3) || B.nb == 0) return hipErrorInvalidValue;
-    GatMhArgs a{N, K, D, ld, ldk, colptr, rowidx};
-    hipLaunchKernelGGL(gatmh_stats_kernel, dim3((N + 3) / 4), dim3(256), 0, s, a, el, er, m, den);
-    const uint32_t nchunk = ld >> 2;
-    const int group = ld >= 128 ? 32 : 16;
-    const uint32_t slabs = (((K * D + 3) >> 2) + group - 1) / group;
-    const uint32_t tiles = (N + GATMH_BLK_ROWS - 1) / GATMH_BLK_ROWS, rounds = (B.nb + 7) / 8;
-    const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
-    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (group == 32)
-        hipLaunchKernelGGL(gatmh_forward_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, el, er, m,
-                           den, partial, tiles, rounds);
-    else
-        hipLaunchKernelGGL(gatmh_forward_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, el, er, m,
-                           den, partial, tiles, rounds);
-    const size_t n = (size_t)N * nchunk;
-    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(gatmh_forward_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den,
-                       o);
-    return hipGetLastError();
 }
 
 // Backward, destination side (CSC): t[v,k] = sum a*da, der[v,k] = sum a*da*l' - t*sum a*l'
@@ -587,301 +406,6 @@ __global__ __launch_bounds__(256) void gatmh_backward_src_eh_kernel(GatMhArgs a,
     }
 }
 
-// ---- backward, source-blocked (same idea as gatmh_forward_blocked_kernel) ------------------------------------
-// K1b's lane mapping: GROUP lanes x float4 cover one 128- or 64-float slab of a row, HL = D/4 neighbouring lanes share
-// a head (a single head spans the whole group), so <dO[v,k,:], Z[u,k,:]> is a 4-term dot per lane plus log2(HL)
-// xor-shuffles inside the head.  Destination side: per-(block, v, k) partial (t, a1, a2); source side: per-block
-// partial dZ rows and partial del; small reduce kernels add the blocks in order, then the self edge.
-__device__ __forceinline__ float head_lanes_sum(float v, int HL) {
-    for (int o = 1; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <int GROUP>
-__global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
-                                                                    const float *el, const float *er,
-                                                                    const float *m_in, const float *den_in,
-                                                                    const float *d_o, float4 *pst /*[nb][N][K]*/,
-                                                                    uint32_t tiles, uint32_t rounds, int HL) {
-    constexpr int RPW = 64 / GROUP;
-    constexpr int BLK_ITER = GATMH_BLK_ROWS / (4 * RPW);
-    const uint32_t id = blockIdx.x;
-    const uint32_t xcd = id & 7u;
-    uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
-    q /= tiles;
-    const uint32_t round = q % rounds;
-    const uint32_t slab = q / rounds;
-    const uint32_t b = round * 8u + xcd;
-    if (b >= B.nb) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane % GROUP, gi = lane / GROUP;
-    const uint32_t nchunk = a.ld >> 2;
-    const uint32_t col = slab * GROUP + li;
-    const bool col_ok = col * 4 < a.K * a.D;
-    const uint32_t ccol = col_ok ? col : 0;
-    const uint32_t k = min((ccol * 4) / a.D, a.K - 1);
-    const float4 *z4 = reinterpret_cast<const float4 *>(z);
-    const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
-    const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
-    const uint64_t base = B.bbase[b];
-#pragma unroll 1
-    for (int it = 0; it < BLK_ITER; ++it) {
-        const uint32_t v = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
-        const bool row_ok = v < a.N;
-        const uint32_t vv = row_ok ? v : 0;
-        uint64_t e = row_ok ? base + boff[v] : 0;
-        const uint64_t end = row_ok ? base + boff[v + 1] : 0;
-        float4 dv = do4[(size_t)vv * nchunk + ccol];
-        if (!col_ok) dv = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float er_v = er[(size_t)vv * a.ldk + k], m_v = m_in[(size_t)vv * a.ldk + k];
-        const float idn = 1.f / den_in[(size_t)vv * a.ldk + k];
-        float t = 0.f, a1 = 0.f, a2 = 0.f;
-        while (e < end) {
-            const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
-            uint32_t my_idx = 0;
-            if (li < n) my_idx = __builtin_nontemporal_load(B.bidx + e + li);
-            for (int j = 0; j < n; j += 4) {
-                float4 x[4];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jj = j + u < n ? j + u : n - 1;      // dead slots repeat the last edge, weight 0 below
-                    const uint32_t s = (uint32_t)__shfl((int)my_idx, jj, GROUP);
-                    x[u] = z4[(size_t)s * nchunk + ccol];
-                    w[u] = el[(size_t)s * a.ldk + k];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float da = dv.x * x[u].x;
-                    da = fmaf(dv.y, x[u].y, da); da = fmaf(dv.z, x[u].z, da); da = fmaf(dv.w, x[u].w, da);
-                    da = head_lanes_sum(da, HL);
-                    const float pre = w[u] + er_v;
-                    const float al = j + u < n ? __expf(lrelu02(pre) - m_v) * idn : 0.f;
-                    const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
-                    t = fmaf(al, da, t);
-                    a1 = fmaf(al * da, lp, a1);
-                    a2 = fmaf(al, lp, a2);
-                }
-            }
-            e += n;
-        }
-        if (row_ok && col_ok && (li % HL) == 0) pst[((size_t)b * a.N + v) * a.K + k] = make_float4(t, a1, a2, 0.f);
-    }
-}
-
-// t, der, st4 = (er, m, 1/den, t): blocks in order, then the self edge
-__global__ void gatmh_bwd_dst_reduce_kernel(GatMhArgs a, uint32_t nb, const float4 *pst, const float *z, const float *el,
-                                            const float *er, const float *m_in, const float *den_in, const float *d_o,
-                                            float *t_out, float *der_out, float4 *st4) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)a.N * a.K) return;
-    const uint32_t v = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
-    float t = 0.f, a1 = 0.f, a2 = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) {
-        const float4 p = pst[((size_t)b * a.N + v) * a.K + k];
-        t += p.x; a1 += p.y; a2 += p.z;
-    }
-    const float *zr = z + (size_t)v * a.ld + (size_t)k * a.D, *dr = d_o + (size_t)v * a.ld + (size_t)k * a.D;
-    float da = 0.f;
-    for (uint32_t d = 0; d < a.D; ++d) da = fmaf(dr[d], zr[d], da);
-    const size_t vk = (size_t)v * a.ldk + k;
-    const float idn = 1.f / den_in[vk];
-    const float pre = el[vk] + er[vk];
-    const float al = __expf(lrelu02(pre) - m_in[vk]) * idn;
-    const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
-    t = fmaf(al, da, t);
-    a1 = fmaf(al * da, lp, a1);
-    a2 = fmaf(al, lp, a2);
-    t_out[vk] = t;
-    der_out[vk] = a1 - t * a2;
-    st4[(size_t)v * a.K + k] = make_float4(er[vk], m_in[vk], idn, t);
-}
-
-template <int GROUP>
-__global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
-                                                                    const float *el, const float4 *st4,
-                                                                    const float *d_o, float *pdz /*[nb][N][ld]*/,
-                                                                    float *pdel /*[nb][N][K]*/, uint32_t tiles,
-                                                                    uint32_t rounds, int HL) {
-    constexpr int RPW = 64 / GROUP;
-    constexpr int BLK_ITER = GATMH_BLK_ROWS / (4 * RPW);
-    const uint32_t id = blockIdx.x;
-    const uint32_t xcd = id & 7u;
-    uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
-    q /= tiles;
-    const uint32_t round = q % rounds;
-    const uint32_t slab = q / rounds;
-    const uint32_t b = round * 8u + xcd;
-    if (b >= B.nb) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane % GROUP, gi = lane / GROUP;
-    const uint32_t nchunk = a.ld >> 2;
-    const uint32_t col = slab * GROUP + li;
-    const bool col_ok = col * 4 < a.K * a.D;
-    const uint32_t ccol = col_ok ? col : 0;
-    const uint32_t k = min((ccol * 4) / a.D, a.K - 1);
-    const float4 *z4 = reinterpret_cast<const float4 *>(z);
-    const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
-    float4 *p4 = reinterpret_cast<float4 *>(pdz) + (size_t)b * a.N * nchunk;
-    const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
-    const uint64_t base = B.bbase[b];
-#pragma unroll 1
-    for (int it = 0; it < BLK_ITER; ++it) {
-        const uint32_t u = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
-        const bool row_ok = u < a.N;
-        const uint32_t uu = row_ok ? u : 0;
-        uint64_t e = row_ok ? base + boff[u] : 0;
-        const uint64_t end = row_ok ? base + boff[u + 1] : 0;
-        float4 zu = z4[(size_t)uu * nchunk + ccol];
-        if (!col_ok) zu = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float el_u = el[(size_t)uu * a.ldk + k];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float del = 0.f;
-        while (e < end) {
-            const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
-            uint32_t my_idx = 0;
-            if (li < n) my_idx = __builtin_nontemporal_load(B.bidx + e + li);
-            for (int j = 0; j < n; j += 4) {
-                float4 x[4], sv[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int jj = j + c < n ? j + c : n - 1;
-                    const uint32_t v = (uint32_t)__shfl((int)my_idx, jj, GROUP);
-                    x[c] = do4[(size_t)v * nchunk + ccol];
-                    sv[c] = st4[(size_t)v * a.K + k];
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float da = zu.x * x[c].x;
-                    da = fmaf(zu.y, x[c].y, da); da = fmaf(zu.z, x[c].z, da); da = fmaf(zu.w, x[c].w, da);
-                    da = head_lanes_sum(da, HL);
-                    const float pre = el_u + sv[c].x;
-                    const float al = j + c < n ? __expf(lrelu02(pre) - sv[c].y) * sv[c].z : 0.f;
-                    const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
-                    del = fmaf(al * (da - sv[c].w), lp, del);
-                    acc.x = fmaf(al, x[c].x, acc.x); acc.y = fmaf(al, x[c].y, acc.y);
-                    acc.z = fmaf(al, x[c].z, acc.z); acc.w = fmaf(al, x[c].w, acc.w);
-                }
-            }
-            e += n;
-        }
-        if (row_ok && col_ok) {
-            p4[(size_t)u * nchunk + col] = acc;
-            if ((li % HL) == 0) pdel[((size_t)b * a.N + u) * a.K + k] = del;
-        }
-    }
-}
-
-// del[u,k] = sum_b pdel + self edge
-__global__ void gatmh_bwd_del_reduce_kernel(GatMhArgs a, uint32_t nb, const float *pdel, const float *z, const float *el,
-                                            const float4 *st4, const float *d_o, float *del_out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)a.N * a.K) return;
-    const uint32_t u = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
-    float del = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) del += pdel[((size_t)b * a.N + u) * a.K + k];
-    const float *zr = z + (size_t)u * a.ld + (size_t)k * a.D, *dr = d_o + (size_t)u * a.ld + (size_t)k * a.D;
-    float da = 0.f;
-    for (uint32_t d = 0; d < a.D; ++d) da = fmaf(dr[d], zr[d], da);
-    const float4 sv = st4[(size_t)u * a.K + k];
-    const float pre = el[(size_t)u * a.ldk + k] + sv.x;
-    const float al = __expf(lrelu02(pre) - sv.y) * sv.z;
-    const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
-    del = fmaf(al * (da - sv.w), lp, del);
-    del_out[(size_t)u * a.ldk + k] = del;
-}
-
-// dz[u,:] = sum_b pdz[b][u,:] + alpha_self dO[u,:] + del[u,k] a_l + der[u,k] a_r
-__global__ __launch_bounds__(256) void gatmh_bwd_dz_reduce_kernel(GatMhArgs a, uint32_t nb, const float *pdz,
-                                                                  const float *el, const float4 *st4, const float *d_o,
-                                                                  const float *del, const float *der, const float *a_l,
-                                                                  const float *a_r, float *dz) {
-    const uint32_t nchunk = a.ld >> 2;
-    const size_t n = (size_t)a.N * nchunk;
-    const float4 *p4 = reinterpret_cast<const float4 *>(pdz);
-    const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t u = (uint32_t)(i / nchunk), col = (uint32_t)(i % nchunk);
-        if (col * 4 >= a.K * a.D) continue;
-        const uint32_t k = min((col * 4) / a.D, a.K - 1);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t b = 0; b < nb; ++b) {
-            const float4 p = p4[(size_t)b * n + i];
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
-        const float4 sv = st4[(size_t)u * a.K + k];
-        const float al = __expf(lrelu02(el[(size_t)u * a.ldk + k] + sv.x) - sv.y) * sv.z;   // self edge
-        const float4 x = do4[i];
-        const float dl = del[(size_t)u * a.ldk + k], dr = der[(size_t)u * a.ldk + k];
-        float r[4] = {fmaf(al, x.x, acc.x), fmaf(al, x.y, acc.y), fmaf(al, x.z, acc.z), fmaf(al, x.w, acc.w)};
-        float *out = dz + (size_t)u * a.ld + (size_t)col * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t f = col * 4 + c;
-            if (f < a.K * a.D) out[c] = r[c] + dl * a_l[f] + dr * a_r[f];
-        }
-    }
-}
-
-// conditions of the blocked backward: one slab per head group, heads aligned to float4 lanes
-static int gatmh_blocked_hl(uint32_t K, uint32_t D, uint32_t ld) {
-    const int group = ld >= 128 ? 32 : 16;
-    if (K == 1) return (ld <= (uint32_t)group * 4) ? group : 0;              // a single head: the whole (one-slab) row
-    if ((D & 3) || (D & (D - 1)) || D / 4 > (uint32_t)group) return 0;
-    return (int)(D / 4);
-}
-
-hipError_t launch_gatmh_backward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
-                                         const BlockedAdj &Bin, const BlockedAdj &Bout, const float *z, const float *el,
-                                         const float *er, const float *m, const float *den, const float *d_o,
-                                         const float *a_l, const float *a_r, float *t, float *del, float *der, float *dz,
-                                         float *partial /*nb x N x (ld + K) floats*/, float4 *st4, hipStream_t s) {
-    if (N == 0) return hipSuccess;
-    const int HL = gatmh_blocked_hl(K, D, ld);
-    if (!HL || !gatmh_shape_ok(K, D) || Bin.nb == 0 || Bout.nb == 0 || 4 * K > ld) return hipErrorInvalidValue;
-    GatMhArgs a{N, K, D, ld, ldk, nullptr, nullptr};
-    const int group = ld >= 128 ? 32 : 16;
-    const uint32_t slabs = (((K * D + 3) >> 2) + group - 1) / group;
-    const uint32_t tiles = (N + GATMH_BLK_ROWS - 1) / GATMH_BLK_ROWS;
-    const int nk_blocks = (int)(((uint64_t)N * K + 255) / 256);
-    const size_t nrow4 = (size_t)N * (ld >> 2);
-    const int row_blocks = (int)((nrow4 + 255) / 256 < 8192 ? (nrow4 + 255) / 256 : 8192);
-    {   // destination side over the in-edges
-        const uint32_t rounds = (Bin.nb + 7) / 8;
-        const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
-        if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        float4 *pst = reinterpret_cast<float4 *>(partial);
-        if (group == 32)
-            hipLaunchKernelGGL(gatmh_bwd_dst_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, el, er, m,
-                               den, d_o, pst, tiles, rounds, HL);
-        else
-            hipLaunchKernelGGL(gatmh_bwd_dst_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, el, er, m,
-                               den, d_o, pst, tiles, rounds, HL);
-        hipLaunchKernelGGL(gatmh_bwd_dst_reduce_kernel, dim3(nk_blocks), dim3(256), 0, s, a, Bin.nb, pst, z, el, er, m, den,
-                           d_o, t, der, st4);
-    }
-    {   // source side over the out-edges
-        const uint32_t rounds = (Bout.nb + 7) / 8;
-        const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
-        if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        float *pdz = partial, *pdel = partial + (size_t)Bout.nb * N * ld;
-        if (group == 32)
-            hipLaunchKernelGGL(gatmh_bwd_src_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bout, z, el, st4,
-                               d_o, pdz, pdel, tiles, rounds, HL);
-        else
-            hipLaunchKernelGGL(gatmh_bwd_src_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bout, z, el, st4,
-                               d_o, pdz, pdel, tiles, rounds, HL);
-        hipLaunchKernelGGL(gatmh_bwd_del_reduce_kernel, dim3(nk_blocks), dim3(256), 0, s, a, Bout.nb, pdel, z, el, st4, d_o,
-                           del);
-        hipLaunchKernelGGL(gatmh_bwd_dz_reduce_kernel, dim3(row_blocks), dim3(256), 0, s, a, Bout.nb, pdz, el, st4, d_o,
-                           del, der, a_l, a_r, dz);
-    }
-    return hipGetLastError();
-}
-
-bool gatmh_backward_blocked_ok(uint32_t K, uint32_t D, uint32_t ld) { return gatmh_blocked_hl(K, D, ld) != 0 && 4 * K <= ld; }
 
 // da[f] = sum_u w[u, f/D] * Z[u,f]   (two stages, deterministic)
 __global__ __launch_bounds__(256) void gatmh_dattn_partial_kernel(uint32_t N, uint32_t KD, uint32_t D,
@@ -963,11 +487,6 @@ hipError_t launch_gatmh_scores(uint32_t N, uint32_t K, uint32_t D, const float *
     return hipGetLastError();
 }
 
-static bool gatmh_shape_ok(uint32_t K, uint32_t D) {
-    if (K == 0 || D == 0 || K > 64 || (uint64_t)K * D > 64 * GATMH_MAXC) return false;
-    if (K == 1) return true;
-    return (D & (D - 1)) == 0 && D <= 64;   // per-head reductions are xor-shuffles inside D lanes
-}
 
 hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                 const uint32_t *rowidx, const float *z, const float *el, const float *er, float *o,
