@@ -278,14 +278,16 @@ def main():
     # ---- the same epoch in the transform-first order of layer 0 (opt-in mode, reported beside the headline) ----
     alt = None
     if world == 1 and not gat and not tf_mode and not args.emulate and not args.opt:
-        ctx.set_option("gcn_transform_first", 1)
+        ctx.set_option("gcn_transform_first", 2)
         if ctx.transform_first_active():
             ctx.timing_enable(False)
             eng.run(max(1, args.warmup))
             alt_ms = eng.run(args.steps)
-            alt = {"layer0_order": "transform-first A(XW) [opt-in: z0 = A(X W0), dW0 = X^T(A^T g0); not the reference order]",
+            nar = [l for l in range(nl) if ctx.transform_first_layer(l)]
+            alt = {"order": "transform-first on layers %s [opt-in gcn_transform_first=2: z_l = A(in_l W_l), dW_l = in_l^T(A^T g_l); "
+                            "not the reference order]" % nar,
                    "ms_per_step": float(np.mean(alt_ms)), "epoch_ms_median": float(np.median(alt_ms)),
-                   "aggregations_per_epoch": "2 x CSC + 2 x CSR, all dims[1] wide"}
+                   "aggregation_widths": [DIMS[l + 1] if l in nar else DIMS[l] for l in range(nl)]}
         ctx.set_option("gcn_transform_first", 0)
 
     if gat or tf_mode or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
-    "dory_gatmh_heads", "dory_transform_first_active",
+    "dory_gatmh_heads", "dory_transform_first_active", "dory_transform_first_layer",
 ]
 
 FORWARD, BACKWARD = 0, 1
@@ -78,6 +78,7 @@ def load():
         "dory_set_option": [vp, cp, C.c_int64],
         "dory_get_option": [vp, cp, C.POINTER(C.c_int64)],
         "dory_transform_first_active": [vp],
+        "dory_transform_first_layer": [vp, u32],
         "dory_epoch_graph_begin": [vp], "dory_epoch_graph_end": [vp], "dory_epoch_graph_launch": [vp, u32],
         "dory_epoch_graph_drop": [vp],
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
@@ -314,6 +315,9 @@ class Context:
 
     def transform_first_active(self):
         return bool(self.lib.dory_transform_first_active(self.h))
+
+    def transform_first_layer(self, layer):
+        return bool(self.lib.dory_transform_first_layer(self.h, int(layer)))
 
     def get_option(self, key):
         v = C.c_int64(0)

@@ -69,9 +69,12 @@ int dory_comm_init(dory_ctx *c, const void *id128, int rank, int nranks) {
 
 // resolve (layer, dir) -> source tensor, ghost tensor, width, as Engine::scatterGCN/GAT do
 static int halo_tensors(dory_ctx *c, uint32_t layer, int dir, Tensor **src, Tensor **ghost) {
-    if (c->gnn == DORY_GCN && layer == 0 && dir == DORY_BACKWARD && tf_active(c)) {
-        *src = find(c, 0, "g");      // transform-first: A^T g0 needs the ghost rows of g0
-        *ghost = find(c, 0, "bgg");
+    if (c->gnn == DORY_GCN && dir == DORY_BACKWARD && tf_layer(c, layer)) {
+        *src = find(c, layer, "g");      // transform-first: A^T g_l needs the ghost rows of g_l
+        *ghost = find(c, layer, "bgg");
+    } else if (c->gnn == DORY_GCN && dir == DORY_FORWARD && layer > 0 && tf_layer(c, layer)) {
+        *src = find(c, layer, "xw");     // transform-first: the already transformed (narrower) rows travel
+        *ghost = find(c, layer, "fgxw");
     } else if (c->gnn == DORY_GCN) {
         if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "halo: layer %u out of range", layer);
         if (dir == DORY_FORWARD) { *src = find(c, layer - 1, "h"); *ghost = find(c, layer, "fg"); }   // gcn_ops.cpp:205-214

@@ -110,13 +110,18 @@ int wait_halo(dory_ctx *c) {
     return DORY_OK;
 }
 
-// Transform-first order for GCN layer 0 (opt-in, no reference counterpart): A(XW0) gathers d1-wide rows
-// instead of the d0-wide rows of (AX)W0 -- 128 instead of 602 floats per edge on Reddit.  The weight gradient
-// follows as X^T(A^T g0): one more d1-wide SpMM on the out-edges.  "ah"@0 is not produced in this mode.
-bool tf_active(dory_ctx *c) {
-    return c->gnn == DORY_GCN && c->L >= 2 && c->dims[0] > c->dims[1] && c->opt["gcn_transform_first"] != 0 &&
-           c->opt["adjacency_values_asymmetric"] == 0;
+// Transform-first order for a GCN layer (opt-in, no reference counterpart): when a layer's input is wider than its
+// output, z_l = A (in_l W_l) gathers d[l+1]-wide rows instead of the d[l]-wide rows of (A in_l) W_l -- 128 instead of
+// 602 floats per edge on Reddit's layer 0, 41 instead of 128 on layer 1.  Backward: u_l = A^T g_l (d[l+1] wide),
+// dW_l = in_l^T u_l, and the gradient handed down is u_l W_l^T (= A^T (g_l W_l^T), the reference's aTg).  "ah"@l is
+// not produced for such a layer.  Option gcn_transform_first: 1 = layer 0 only, 2 = every layer that narrows.
+bool tf_layer(dory_ctx *c, uint32_t layer) {
+    const int64_t mode = c->opt["gcn_transform_first"];
+    if (c->gnn != DORY_GCN || c->L < 2 || layer >= c->L || mode == 0 || c->opt["adjacency_values_asymmetric"] != 0) return false;
+    if (mode == 1 && layer != 0) return false;
+    return c->dims[layer] > c->dims[layer + 1];
 }
+bool tf_active(dory_ctx *c) { return tf_layer(c, 0); }
 
 }  // namespace dory
 
@@ -157,7 +162,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
-    c->opt["gcn_transform_first"] = 0;   // GCN layer 0 as A(XW) instead of (AX)W when the input is wider than the output (see tf_active)
+    c->opt["gcn_transform_first"] = 0;   // GCN layers as A(XW) instead of (AX)W where the input is wider than the output: 1 = layer 0, 2 = all (see tf_layer)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
     *out = c;
@@ -335,11 +340,12 @@ int dory_preallocate(dory_ctx *c) {
             mk(l - 1, "bg", c->Gdst, d[l]);
             mk(l - 1, "aTg", N, d[l]);
         }
-        if (L >= 2 && d[0] > d[1]) {   // transform-first order of layer 0 (option gcn_transform_first)
-            mk(0, "xw", N, d[1]);          // X W0
-            mk(0, "fgxw", c->Gsrc, d[1]);  // the same for the layer-0 ghost rows
-            mk(0, "u", N, d[1]);           // A^T g0
-            mk(0, "bgg", c->Gdst, d[1]);   // ghost rows of g0 (backward exchange at layer 0)
+        for (uint32_t l = 0; l < L && L >= 2; ++l) {   // transform-first order (option gcn_transform_first)
+            if (d[l] <= d[l + 1]) continue;
+            mk(l, "xw", N, d[l + 1]);          // in_l W_l
+            mk(l, "fgxw", c->Gsrc, d[l + 1]);  // its ghost rows (layer 0: transformed locally from fg@0, else exchanged)
+            mk(l, "u", N, d[l + 1]);           // A^T g_l
+            mk(l, "bgg", c->Gdst, d[l + 1]);   // ghost rows of g_l (backward exchange)
         }
     } else if (c->gnn == DORY_GATMH) {  // extension (no reference counterpart): see dory_gatmh_heads
         if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only in this version");
@@ -628,7 +634,16 @@ int dory_timing_reset(dory_ctx *c) {
 int dory_transform_first_active(dory_ctx *c) {
     if (!c) return 0;
     std::lock_guard<std::mutex> lock(c->mu);
-    return c->configured && tf_active(c) ? 1 : 0;
+    if (!c->configured) return 0;
+    for (uint32_t l = 0; l < c->L; ++l)
+        if (tf_layer(c, l)) return 1;
+    return 0;
+}
+
+int dory_transform_first_layer(dory_ctx *c, uint32_t layer) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    return c->configured && tf_layer(c, layer) ? 1 : 0;
 }
 
 int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {

@@ -89,8 +89,9 @@ int upload_array(dory_ctx *c, T **dst, const T *src, uint64_t n) {
 // Ghost rows of the last halo exchange land on the comm stream; with "halo_overlap" the compute stream is only
 // made to wait for them (event ev_b) by the first consumer.
 int wait_halo(dory_ctx *c);
-// transform-first order of GCN layer 0 applies (option, model shape, adjacency values): see abi_context.hip
-bool tf_active(dory_ctx *c);
+// transform-first order applies to this GCN layer (option, model shape, adjacency values): see abi_context.hip
+bool tf_layer(dory_ctx *c, uint32_t layer);
+bool tf_active(dory_ctx *c);   // = tf_layer(c, 0)
 // K1b bookkeeping (abi_stages.hip)
 int ensure_blocked(dory_ctx *c, bool csc, int group);
 int blk_group_for(dory_ctx *c, uint32_t ld);

@@ -124,21 +124,29 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             NEED(fg, layer, "fg");
             NEED(ah, layer, "ah");
             if (!in) return fail(c, DORY_ERR_ARG, "aggregate: input tensor missing");
-            if (layer == 0 && tf_active(c)) {   // z0 = A (X W0): transform the local and the ghost rows, then gather d1-wide
-                NEED(xw, 0, "xw"); NEED(fgxw, 0, "fgxw"); NEED(z, 0, "z");
-                Tensor &W = c->weights[0]["w"];
-                int rc = gemm(c, 0, 0, c->N, c->dims[1], c->dims[0], *in, W, *xw);
-                if (!rc && c->Gsrc) rc = gemm(c, 0, 0, c->Gsrc, c->dims[1], c->dims[0], *fg, W, *fgxw);
-                if (rc) return rc;
-                return spmm(c, true, c->cscVal, 1, *xw, fgxw, *z, c->dims[1], 0);
+            if (tf_layer(c, layer)) {   // z_l = A (in_l W_l): gather d[l+1]-wide
+                NEED(xw, layer, "xw"); NEED(fgxw, layer, "fgxw"); NEED(z, layer, "z");
+                if (layer == 0) {   // the input and its ghost rows are static: transform both here
+                    Tensor &W = c->weights[0]["w"];
+                    int rc = gemm(c, 0, 0, c->N, c->dims[1], c->dims[0], *in, W, *xw);
+                    if (!rc && c->Gsrc) rc = gemm(c, 0, 0, c->Gsrc, c->dims[1], c->dims[0], *fg, W, *fgxw);
+                    if (rc) return rc;
+                }   // deeper layers: apply_vertex(l-1) left xw@l, the forward exchange of layer l its ghost rows
+                return spmm(c, true, c->cscVal, 1, *xw, fgxw, *z, c->dims[layer + 1], 0);
             }
             return spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
         }
-        if (layer == 0 && tf_active(c)) {   // dW0 = X^T (A^T g0)   (ghost rows of g0: halo exchange (0, backward))
-            NEED(g, 0, "g"); NEED(bgg, 0, "bgg"); NEED(u, 0, "u"); NEED(x, 0, "x");
-            int rc = spmm(c, false, c->csrVal, 1, *g, bgg, *u, c->dims[1], 0);
+        if (tf_layer(c, layer)) {   // u_l = A^T g_l (ghost rows of g_l: backward exchange of layer l); dW_l = in_l^T u_l
+            NEED(g, layer, "g"); NEED(bgg, layer, "bgg"); NEED(u, layer, "u");
+            Tensor *in = layer == 0 ? find(c, 0, "x") : find(c, layer - 1, "h");
+            if (!in) return fail(c, DORY_ERR_ARG, "aggregate: input tensor missing");
+            const uint32_t Fin = c->dims[layer], Fout = c->dims[layer + 1];
+            int rc = spmm(c, false, c->csrVal, 1, *g, bgg, *u, Fout, 0);
             if (rc) return rc;
-            return gemm(c, 1, 0, c->dims[0], c->dims[1], c->N, *x, *u, c->wgrads[0]["w"]);
+            if ((rc = gemm(c, 1, 0, Fin, Fout, c->N, *in, *u, c->wgrads[layer]["w"]))) return rc;
+            if (layer == 0) return DORY_OK;
+            NEED(aTg, layer - 1, "aTg");   // the gradient handed down: A^T (g_l W_l^T) = u_l W_l^T
+            return gemm(c, 0, 1, c->N, Fin, Fout, *u, c->weights[layer]["w"], *aTg);
         }
         if (layer == 0 || layer >= c->L) return fail(c, DORY_ERR_ARG, "aggregate backward: layer %u out of range", layer);
         NEED(grad, layer, "grad");
@@ -251,16 +259,22 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
         if (dir == DORY_FORWARD) {
             if (layer != c->L - 1) {  // vtxNNForwardGCN hidden (CPU_comm.cpp:98-107)
                 NEED(h, layer, "h");
-                if (layer == 0 && tf_active(c)) {   // z0 came out of dory_aggregate already
+                if (tf_layer(c, layer)) {   // z_l came out of dory_aggregate already
                     Timed t(c, "loss", c->compute);
                     HIPCK(c, launch_tanh_forward(N, Fout, z->d, z->ld, h->d, h->ld, c->compute));
-                    return DORY_OK;
+                } else if ((rc = gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z, h))) {
+                    return rc;
                 }
-                return gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z, h);
+                if (tf_layer(c, layer + 1)) {   // the next layer gathers (h_l W_{l+1}): transform before the exchange
+                    NEED(xwn, layer + 1, "xw");
+                    return gemm(c, 0, 0, N, c->dims[layer + 2], Fout, *h, c->weights[layer + 1]["w"], *xwn);
+                }
+                return DORY_OK;
             }
             // last layer (CPU_comm.cpp:108-133)
             NEED(lab, layer, "lab");
-            if ((rc = gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z))) return rc;
+            const bool tfl = tf_layer(c, layer);   // then z_l came out of dory_aggregate, and dW_l / the handed-down gradient follow there
+            if (!tfl && (rc = gemm(c, 0, 0, N, Fout, Fin, *ah, W, *z))) return rc;
             const uint32_t stt = (uint32_t)(N * 0.66);            // TRAIN_PORTION
             const uint32_t vend = stt + (uint32_t)(N * 0.1);      // VAL_PORTION
             c->val_rows = vend - stt;
@@ -273,6 +287,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
                                              vend, (uint64_t)stt * Fout, (uint64_t)(N - stt), c->d_stat,
                                              c->scratch, c->compute));
             }
+            if (tfl) return DORY_OK;
             if (layer > 0) {  // interGrad = d_output * W^T -> "grad"
                 NEED(grad, layer, "grad");
                 if ((rc = gemm(c, 0, 1, N, Fin, Fout, *g, W, *grad))) return rc;
@@ -285,7 +300,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
             Timed t(c, "loss", c->compute);
             HIPCK(c, launch_tanh_backward(N, Fout, aTg->d, aTg->ld, z->d, z->ld, g->d, g->ld, c->compute));
         }
-        if (layer == 0 && tf_active(c)) return DORY_OK;   // dW0 follows in dory_aggregate(0, backward)
+        if (tf_layer(c, layer)) return DORY_OK;   // dW_l (and the gradient for layer l-1) follow in dory_aggregate(l, backward)
         if ((rc = gemm(c, 1, 0, Fin, Fout, N, *ah, *g, dW))) return rc;
         if (layer != 0) {
             NEED(grad, layer, "grad");

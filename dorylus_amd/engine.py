@@ -79,17 +79,16 @@ class Engine:
             # weight updates leave for the "weight server" right after the stage that
             # produced them (CPU_comm.cpp:131,147): all-reduce + Adam on the device
             if self.gnn_type == GCN:
-                tf0 = c.layer == 0 and c.dir == BACKWARD and self._transform_first()
-                if (c.dir == BACKWARD or c.layer == self.numLayers - 1) and not tf0:
-                    self.ctx.weight_update(c.layer)
+                if (c.dir == BACKWARD or c.layer == self.numLayers - 1) and not self._transform_first(c.layer):
+                    self.ctx.weight_update(c.layer)          # transform-first layers: after their backward aggregation
             elif c.dir == BACKWARD:
                 self.ctx.weight_update(c.layer)
         else:
             self.ctx.apply_edge(c.layer, c.dir)
 
-    def _transform_first(self):
-        f = getattr(self.ctx, "transform_first_active", None)
-        return bool(f()) if f else False
+    def _transform_first(self, layer):
+        f = getattr(self.ctx, "transform_first_layer", None)
+        return bool(f(layer)) if f else False
 
     def applyVertexGCN(self, c):   # gcn_ops.cpp:194-202
         c.vertex = True
@@ -129,9 +128,11 @@ class Engine:
         if self.gnn_type == GCN:
             while True:
                 self.aggregateGCN(c)                       # GA
+                if c.dir == BACKWARD and self._transform_first(c.layer):
+                    self.ctx.weight_update(c.layer)        # transform-first: this aggregation produced dW_l
                 c = self.applyVertexGCN(c)                 # AV (+ NNRecvCallbackGCN below)
                 if self.isLastLayer(c):
-                    if self._transform_first():            # dW0 = X^T (A^T g0): see include/dorylus_hip.h
+                    if self._transform_first(0):           # dW0 = X^T (A^T g0): see include/dorylus_hip.h
                         self.scatterGCN(c)
                         self.aggregateGCN(c)
                         self.ctx.weight_update(0)

@@ -58,8 +58,9 @@ class HIPComm : public ResourceComm {
             bool produced = gnn_ == DORY_GCN
                                 ? (chunk.dir == DORY_BACKWARD || chunk.layer == totalLayers_ - 1)
                                 : (chunk.dir == DORY_BACKWARD);
-            // transform-first order: dW0 only exists after the extra aggregation Engine::runEpoch issues
-            if (produced && chunk.layer == 0 && chunk.dir == DORY_BACKWARD && dory_transform_first_active(ctx_)) produced = false;
+            // transform-first order of this layer: dW_l only exists after the backward aggregation of layer l
+            // (Engine::runEpoch sends the update then)
+            if (produced && dory_transform_first_layer(ctx_, chunk.layer)) produced = false;
             if (produced && (rc = dory_weight_update(ctx_, chunk.layer))) return rc;
             return DORY_OK;
         }
@@ -174,9 +175,12 @@ class Engine {
         if (gnn_type == DORY_GCN) {
             for (;;) {
                 if ((rc = aggregateGCN(c))) return rc;          // GA
+                if (!trace && c.dir == DORY_BACKWARD && dory_transform_first_layer(ctx, c.layer) &&
+                    (rc = dory_weight_update(ctx, c.layer)))    // transform-first: this aggregation produced dW_l
+                    return rc;
                 if ((rc = applyVertexGCN(c))) return rc;        // AV -> NNRecvCallbackGCN
                 if (isLastLayer(c)) {                           //   -> schQueue (next epoch)
-                    if (!trace && dory_transform_first_active(ctx)) {
+                    if (!trace && dory_transform_first_layer(ctx, 0)) {
                         // transform-first order of layer 0 (dorylus_hip.h): dW0 = X^T (A^T g0) needs g0's ghost
                         // rows and one more aggregation on the out-edges before the update can leave
                         if ((rc = scatterGCN(c))) return rc;

@@ -203,6 +203,14 @@ int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
  * sets the option "adjacency_values_asymmetric" and the mode stays off (a direct dory_graph_upload caller sets it
  * itself).  Returns 1 when the mode applies to the configured model and graph, else 0. */
 int dory_transform_first_active(dory_ctx *ctx);
+/* With "gcn_transform_first" = 2 every layer whose input is wider than its output runs in this order (Reddit: both
+ * layers -- aggregations of 128, 41, 41 and 128 floats per edge instead of 602, 128, 128).  For such a layer l > 0:
+ * dory_apply_vertex(l-1, FORWARD) also leaves "xw"@l = h_{l-1} W_l, the forward exchange of layer l ships those
+ * (narrower) rows, dory_aggregate(l, FORWARD) writes "z"@l, the backward exchange of layer l ships g_l, and
+ * dory_aggregate(l, BACKWARD) forms u_l = A^T g_l, dW_l = h_{l-1}^T u_l and "aTg"@(l-1) = u_l W_l^T; the weight
+ * update of layer l follows that call.  dory_transform_first_active reports whether any layer is in this mode,
+ * dory_transform_first_layer a particular one. */
+int dory_transform_first_layer(dory_ctx *ctx, uint32_t layer);
 
 /* Epoch graph (MI355X-side addition, no reference counterpart): record the calls of one
  * epoch -- dory_aggregate / dory_apply_vertex / dory_apply_edge / dory_predict_gat /

@@ -136,7 +136,7 @@ def test_aggregate_feature_slabs(da, slab):
     ctx.close()
 
 
-def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None, transform_first=False):
+def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None, transform_first=0):
     """P partitions as P contexts on one GPU; the transport between them is a host
     copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
     import torch
@@ -167,7 +167,11 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
 
     def exchange(layer, d):
         # widths travel padded (ld); transport = device-to-device copies by torch
-        src_name, src_layer = ("h", layer - 1) if d == 0 else ("grad", layer) if layer > 0 else ("g", 0)
+        tfl = ctxs[0].transform_first_layer(layer)
+        if d == 0:
+            src_name, src_layer = ("xw", layer) if tfl else ("h", layer - 1)
+        else:
+            src_name, src_layer = ("g", layer) if tfl else ("grad", layer)
         _, _, ld, _ = ctxs[0].info(src_layer, src_name)
         send = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][0])) * ld, device="cuda") for r in range(P)]
         recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][1])) * ld, device="cuda") for r in range(P)]
@@ -197,17 +201,17 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
                 c.apply_vertex(l, da.FORWARD)
         stats.append([c.train_stat() for c in ctxs])
         dWs = {}
-        dWs[L - 1] = sum(c.weight_grad_get(L - 1) for c in ctxs)
         for l in range(L - 1, 0, -1):
             exchange(l, da.BACKWARD)
             for c in ctxs:
                 c.aggregate(l, da.BACKWARD)
                 c.apply_vertex(l - 1, da.BACKWARD)
-            if l == 1 and ctxs[0].transform_first_active():
-                exchange(0, da.BACKWARD)              # ghost rows of g0
-                for c in ctxs:
-                    c.aggregate(0, da.BACKWARD)       # dW0 = X^T (A^T g0)
-            dWs[l - 1] = sum(c.weight_grad_get(l - 1) for c in ctxs)
+        if ctxs[0].transform_first_layer(0):
+            exchange(0, da.BACKWARD)              # ghost rows of g0
+            for c in ctxs:
+                c.aggregate(0, da.BACKWARD)       # dW0 = X^T (A^T g0)
+        for l in range(L):                        # every gradient exists now, whichever stage produced it
+            dWs[l] = sum(c.weight_grad_get(l) for c in ctxs)
         if epochs > 1:
             for c in ctxs:
                 for l in range(L - 1, -1, -1):
@@ -282,7 +286,8 @@ def test_gcn_epoch_vs_oracle(da, case, dims):
     ("parts_toy60_p4_hash", [300, 64, 64, 25]),      # 3 layers: only layer 0 changes order
     ("parts_toy40_p3_empty", [20, 12, 4]),
 ])
-def test_gcn_epoch_transform_first_vs_oracle(da, case, dims):
+@pytest.mark.parametrize("mode", [1, 2])    # 1: layer 0 only, 2: every layer that narrows
+def test_gcn_epoch_transform_first_vs_oracle(da, case, dims, mode):
     """Option gcn_transform_first: z0 = A(X W0), dW0 = X^T(A^T g0) -- every tensor the reference order also
     produces (all but ah0) and the summed weight gradients against the same oracle epoch, P partitions."""
     from helpers import oracle_gcn_epoch, rel_err
@@ -293,15 +298,18 @@ def test_gcn_epoch_transform_first_vs_oracle(da, case, dims):
     labels = rng.integers(0, dims[-1], V).astype(np.uint32)
     Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)
           for i in range(len(dims) - 1)]
-    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, transform_first=True)
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, transform_first=mode)
     assert ctxs[0].transform_first_active()
+    tfl = [ctxs[0].transform_first_layer(l) for l in range(len(dims) - 1)]
+    assert tfl[0] and (mode == 2 or not any(tfl[1:]))
+    assert tfl == [mode == 2 and dims[l] > dims[l + 1] or (l == 0) for l in range(len(dims) - 1)]
     T, dW = oracle_gcn_epoch(gs, parts, X, labels, Ws, V)
     L = len(dims) - 1
     for r, c in enumerate(ctxs):
         if gs[r]["localVtxCnt"] == 0:
             continue
         for l in range(L):
-            if l > 0:
+            if not tfl[l]:
                 assert rel_err(c.download(l, "ah"), T[r][f"ah{l}"]) < RTOL, (r, l, "ah")
             if l < L - 1:
                 assert rel_err(c.download(l, "z"), T[r][f"z{l}"]) < RTOL, (r, l, "z")
@@ -325,7 +333,7 @@ def test_transform_first_engine_epochs_match_reference_order(da):
     s, d = rng.integers(0, V, E), rng.integers(0, V, E)
     g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
     out = {}
-    for tf in (0, 1):
+    for tf in (0, 1, 2):
         ctx = da.Context(0)
         ctx.configure(da.GCN, [96, 32, 6], V)
         ctx.set_option("gcn_transform_first", tf)
@@ -341,8 +349,9 @@ def test_transform_first_engine_epochs_match_reference_order(da):
         out[tf] = [ctx.weight_get(l, "w") for l in range(2)] + [ctx.download(0, "h")]
         eng.close()
         ctx.close()
-    for a, b in zip(out[0], out[1]):
-        assert rel_err(a, b) < 1e-4
+    for tf in (1, 2):
+        for a, b in zip(out[0], out[tf]):
+            assert rel_err(a, b) < 1e-4, tf
     ctx = da.Context(0)
     ctx.configure(da.GCN, [16, 32, 6], V)
     ctx.set_option("gcn_transform_first", 1)
