@@ -14,6 +14,8 @@ RTOL = 1e-4
     ([16, 64, 7], [1, 1], 150, 900),         # single head: reductions span the whole row
     ([20, 128, 5], [4, 1], 180, 1300),       # 4 heads x 32
     ([12, 100, 6], [1, 1], 160, 1100),       # one head of 100 features: split over 4 lanes, last piece ragged
+    ([24, 256, 6], [4, 1], 170, 1200),       # 4 heads x 64: two 128-float slabs per row
+    ([24, 256, 9], [32, 1], 140, 1000),      # 32 heads x 8
 ])
 @pytest.mark.parametrize("nb", [0, 8])    # 8: force the source-blocked forward on these L2-sized graphs
 def test_gat_mh_epoch_vs_oracle(dims, heads, V, E, nb):
