@@ -12,7 +12,7 @@
 //   NT  grad = d  * W^T
 //   TN  dW   = ah^T * d        reduction over M: split-K over workgroups with a
 //                              deterministic second-stage sum (no atomics)
-// Tiling: 128 x BN block (BN = 128 or 64), BK = 32, 4 waves, each wave a
+// Tiling: 128 x BN block (BN = 128 or 64), BK = 16, 4 waves, each wave a
 // 64x64 (2x2 MFMA tiles) or 32x64 (1x2) register tile.  Both operands are staged
 // k-major in LDS (As[k][i], Bs[k][j]) so every fragment read is a conflict-free
 // ds_read_b32 of 32 consecutive floats per half-wave.
@@ -23,7 +23,7 @@ namespace dory {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 32;
+constexpr int BK = 16;   // 34 KB of LDS per workgroup -> 4 workgroups per CU (BK = 32: 2 per CU, 7 % slower end to end)
 
 // A (BK x BT) operand tile travels global -> registers -> LDS (k-major).  The two halves
 // are separate so that the loads of tile t+1 are in flight while tile t is multiplied.
@@ -107,7 +107,7 @@ __device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR
 }
 
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 1;
     constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 1;
