@@ -109,8 +109,10 @@ __device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 1;
-    constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 1;
+    // row-major operands are transposed on their way into LDS: 4 k-lanes x 8 rows per 32-lane group write
+    // (kq + c) * LD + rr with kq in {0,4,8,12}, rr in 0..7 -> LD = 2 (mod 32) keeps the 32 banks distinct
+    constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 2;
+    constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 2;
     constexpr int A_SZ = (BK * LDA_S + 3) & ~3;
     constexpr int B_SZ = (BK * LDB_S + 3) & ~3;
     // two LDS buffers per operand: tile t+1 is written while nobody reads it, one barrier per tile
