@@ -279,7 +279,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
             const uint32_t vend = stt + (uint32_t)(N * 0.1);      // VAL_PORTION
             c->val_rows = vend - stt;
             const float denom = (float)(c->globalV * 0.66);
-            if ((rc = ensure_scratch(c, (size_t)(2 * ((vend - stt + 255) / 256) + 64) * sizeof(float)))) return rc;
+            if ((rc = ensure_scratch(c, softmax_xent_scratch_bytes(Fout, vend - stt)))) return rc;
             {
                 Timed t(c, "loss", c->compute);
                 // maskout copies (N - stt) floats starting at dense offset stt*cols (CPU_comm.cpp:464-471)

@@ -191,6 +191,7 @@ hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, 
 hipError_t launch_tanh_forward(uint64_t rows, uint32_t cols, const float *z, uint32_t ldz, float *h, uint32_t ldh,
                                hipStream_t s);
 // softmax + validation stats + maskout quirk + (p - lab)/denom  (CPU_comm.cpp:108-122)
+size_t softmax_xent_scratch_bytes(uint32_t cols, uint32_t val_rows);
 hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
                                const float *lab, uint32_t ldl, float *d, uint32_t ldd,
                                float denom, uint32_t val_stt, uint32_t val_end,

@@ -77,24 +77,30 @@ hipError_t launch_tanh_forward(uint64_t rows, uint32_t cols, const float *z, uin
 // flat dense-index range), hadamardSub + "/= globalVtxCnt * TRAIN_PORTION"
 // (CPU_comm.cpp:121-122).  CUDA backend: cudnnSoftmaxForward + thrust minus +
 // cublasSscal + cudaMemcpy maskout (comp_unit.cu:161-210,331-346).
-// One wave per row; lane c owns columns c, c+64, ...
+// LPR lanes per row (64, 32, 16 or 8: the smallest that holds a row of up to 64 / 32 / 16 / 8 classes, so a wave
+// covers 1-8 rows and no lane idles on narrow label sets); lane c owns columns c, c+LPR, ...  The xor-shuffle trees
+// descend from LPR/2, i.e. the sums are the ones the 64-lane tree gives with the unused lanes at zero.
+template <int LPR>
 __global__ __launch_bounds__(256) void softmax_xent_kernel(
     uint32_t rows, uint32_t cols, const float *z, uint32_t ldz, const float *lab, uint32_t ldl,
     float *d, uint32_t ldd, float inv_mode_denom, uint64_t mask_first, uint64_t mask_count,
     int sub_only) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % LPR;
+    const uint32_t row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (row >= rows) return;
     const float *zr = z + (size_t)row * ldz;
     float mx = -INFINITY;
-    for (uint32_t c = lane; c < cols; c += 64) mx = fmaxf(mx, zr[c]);
-    mx = wave_max(mx);
+    for (uint32_t c = lane; c < cols; c += LPR) mx = fmaxf(mx, zr[c]);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.f;
-    for (uint32_t c = lane; c < cols; c += 64) sum += expf(zr[c] - mx);
-    sum = wave_sum(sum) + 1e-20f;
+    for (uint32_t c = lane; c < cols; c += LPR) sum += expf(zr[c] - mx);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum += 1e-20f;
     const float *lr = lab + (size_t)row * ldl;
     float *dr = d + (size_t)row * ldd;
-    for (uint32_t c = lane; c < cols; c += 64) {
+    for (uint32_t c = lane; c < cols; c += LPR) {
         float p = expf(zr[c] - mx) / sum;
         const float l = lr[c];
         if (sub_only) {  // predictGAT (engine/ops/gat_ops.cpp:246-265): softmax - label
@@ -107,35 +113,90 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(
     }
 }
 
+static void launch_softmax_rows(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz, const float *lab,
+                                uint32_t ldl, float *d, uint32_t ldd, float denom, uint64_t mask_first,
+                                uint64_t mask_count, int sub_only, hipStream_t s) {
+#define SOFTMAX_LPR(L)                                                                                              \
+    hipLaunchKernelGGL(softmax_xent_kernel<L>, dim3((rows + 256 / L - 1) / (256 / L)), dim3(256), 0, s, rows, cols, z, \
+                       ldz, lab, ldl, d, ldd, denom, mask_first, mask_count, sub_only)
+    if (cols <= 8) SOFTMAX_LPR(8);
+    else if (cols <= 16) SOFTMAX_LPR(16);
+    else if (cols <= 32) SOFTMAX_LPR(32);
+    else SOFTMAX_LPR(64);
+#undef SOFTMAX_LPR
+}
+
 // CPUComm::getTrainStat (CPU_comm.cpp:448-462): over validation rows
 // [val_stt, val_end): acc += lab[argmax(pred)], loss -= log(pred[argmax(lab)]).
-// One row per thread, per-block tree sums, then one block adds the block partials
-// in index order -> deterministic.  (thrust functors in the CUDA backend:
-// comp_unit.cu:258-312, cuda_ops.cuh:45-113.)
+// One row per thread with the reference's own sequential arithmetic, but the rows of a block are staged through
+// LDS with coalesced loads first (a thread reading its row straight from HBM touches 64 lines per instruction);
+// per-block tree sums, then one block adds the block partials in a fixed order -> deterministic.  (thrust functors
+// in the CUDA backend: comp_unit.cu:258-312, cuda_ops.cuh:45-113.)
+constexpr int STAT_ROWS_MAX = 64;   // rows per block (fewer when the label set is so wide that 64 rows do not fit LDS)
+static uint32_t stat_rows_per_block(uint32_t cols) {
+    uint32_t rb = STAT_ROWS_MAX;
+    while (rb > 1 && (size_t)2 * rb * (cols + 1) * sizeof(float) > 48 * 1024) rb >>= 1;
+    return rb;
+}
 __global__ __launch_bounds__(256) void train_stat_kernel(uint32_t cols, const float *z, uint32_t ldz,
                                                          const float *lab, uint32_t ldl,
                                                          uint32_t val_stt, uint32_t val_end,
-                                                         float *partial) {
-    __shared__ float sa[256], sl[256];
-    float acc = 0.f, loss = 0.f;
-    const uint32_t r = val_stt + blockIdx.x * 256 + threadIdx.x;
-    if (r < val_end) {
-        const float *zr = z + (size_t)r * ldz;
-        const float *lr = lab + (size_t)r * ldl;
-        float mx = zr[0];
-        uint32_t am = 0, al = 0;
-        float lmax = lr[0];
-        for (uint32_t c = 1; c < cols; ++c) {
-            if (zr[c] > mx) { mx = zr[c]; am = c; }      // argmax(pred) == argmax(z), first max
-            if (lr[c] > lmax) { lmax = lr[c]; al = c; }
-        }
-        float den = 1e-20f;
-        for (uint32_t c = 0; c < cols; ++c) den += expf(zr[c] - mx);
-        acc = lr[am];
-        loss = -logf(expf(zr[al] - mx) / den);
+                                                         float *partial, uint32_t STAT_ROWS) {
+    extern __shared__ float sm[];            // [STAT_ROWS][cols+1] z, then the same for lab
+    const uint32_t pitch = cols + 1;
+    float *sz = sm, *sl = sm + STAT_ROWS * pitch;
+    const uint32_t r0 = val_stt + blockIdx.x * STAT_ROWS;
+    for (uint32_t i = threadIdx.x; i < STAT_ROWS * cols; i += 256) {
+        const uint32_t rr = i / cols, c = i % cols;
+        const uint32_t r = r0 + rr;
+        sz[rr * pitch + c] = r < val_end ? z[(size_t)r * ldz + c] : 0.f;
+        sl[rr * pitch + c] = r < val_end ? lab[(size_t)r * ldl + c] : 0.f;
     }
-    sa[threadIdx.x] = acc;
-    sl[threadIdx.x] = loss;
+    __syncthreads();
+    __shared__ float sa[STAT_ROWS_MAX], sls[STAT_ROWS_MAX];
+    if (threadIdx.x < STAT_ROWS) {
+        float acc = 0.f, loss = 0.f;
+        if (r0 + threadIdx.x < val_end) {
+            const float *zr = sz + threadIdx.x * pitch;
+            const float *lr = sl + threadIdx.x * pitch;
+            float mx = zr[0];
+            uint32_t am = 0, al = 0;
+            float lmax = lr[0];
+            for (uint32_t c = 1; c < cols; ++c) {
+                if (zr[c] > mx) { mx = zr[c]; am = c; }      // argmax(pred) == argmax(z), first max
+                if (lr[c] > lmax) { lmax = lr[c]; al = c; }
+            }
+            float den = 1e-20f;
+            for (uint32_t c = 0; c < cols; ++c) den += expf(zr[c] - mx);
+            acc = lr[am];
+            loss = -logf(expf(zr[al] - mx) / den);
+        }
+        sa[threadIdx.x] = acc;
+        sls[threadIdx.x] = loss;
+    }
+    __syncthreads();
+    for (int o = (int)STAT_ROWS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sa[threadIdx.x] += sa[threadIdx.x + o];
+            sls[threadIdx.x] += sls[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sa[0];
+        partial[2 * blockIdx.x + 1] = sls[0];
+    }
+}
+// one block: thread t adds partials t, t+256, ... in order, then a fixed tree over the 256 threads
+__global__ __launch_bounds__(256) void train_stat_final_kernel(const float *partial, uint32_t nb, float *stat) {
+    __shared__ float sa[256], sl[256];
+    float a = 0.f, l = 0.f;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        a += partial[2 * b];
+        l += partial[2 * b + 1];
+    }
+    sa[threadIdx.x] = a;
+    sl[threadIdx.x] = l;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
@@ -145,20 +206,14 @@ __global__ __launch_bounds__(256) void train_stat_kernel(uint32_t cols, const fl
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = sa[0];
-        partial[2 * blockIdx.x + 1] = sl[0];
+        stat[0] = sa[0];
+        stat[1] = sl[0];
     }
 }
-__global__ void train_stat_final_kernel(const float *partial, uint32_t nb, float *stat) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f, l = 0.f;
-        for (uint32_t b = 0; b < nb; ++b) {
-            a += partial[2 * b];
-            l += partial[2 * b + 1];
-        }
-        stat[0] = a;
-        stat[1] = l;
-    }
+
+size_t softmax_xent_scratch_bytes(uint32_t cols, uint32_t val_rows) {   // per-block partials of the validation statistics
+    const uint32_t rb = stat_rows_per_block(cols);
+    return (size_t)(2 * ((val_rows + rb - 1) / rb) + 64) * sizeof(float);
 }
 
 hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
@@ -166,21 +221,20 @@ hipError_t launch_softmax_xent(uint32_t rows, uint32_t cols, const float *z, uin
                                uint32_t val_stt, uint32_t val_end, uint64_t mask_first,
                                uint64_t mask_count, float *stat, float *stat_partial, hipStream_t s) {
     if (rows == 0) return hipSuccess;
-    const uint32_t nb = (val_end - val_stt + 255) / 256;
+    const uint32_t rb = stat_rows_per_block(cols);
+    const uint32_t nb = (val_end - val_stt + rb - 1) / rb;
     if (nb)
-        hipLaunchKernelGGL(train_stat_kernel, dim3(nb), dim3(256), 0, s, cols, z, ldz, lab, ldl, val_stt,
-                           val_end, stat_partial);
-    hipLaunchKernelGGL(train_stat_final_kernel, dim3(1), dim3(64), 0, s, stat_partial, nb, stat);
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, rows, cols, z, ldz,
-                       lab, ldl, d, ldd, denom, mask_first, mask_count, 0);
+        hipLaunchKernelGGL(train_stat_kernel, dim3(nb), dim3(256), (size_t)2 * rb * (cols + 1) * sizeof(float), s, cols, z,
+                           ldz, lab, ldl, val_stt, val_end, stat_partial, rb);
+    hipLaunchKernelGGL(train_stat_final_kernel, dim3(1), dim3(256), 0, s, stat_partial, nb, stat);
+    launch_softmax_rows(rows, cols, z, ldz, lab, ldl, d, ldd, denom, mask_first, mask_count, 0, s);
     return hipGetLastError();
 }
 
 hipError_t launch_softmax_sub(uint32_t rows, uint32_t cols, const float *z, uint32_t ldz,
                               const float *lab, uint32_t ldl, float *out, uint32_t ldo, hipStream_t s) {
     if (rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, rows, cols, z, ldz,
-                       lab, ldl, out, ldo, 1.f, (uint64_t)0, (uint64_t)0, 1);
+    launch_softmax_rows(rows, cols, z, ldz, lab, ldl, out, ldo, 1.f, 0, 0, 1, s);
     return hipGetLastError();
 }
 
