@@ -23,19 +23,22 @@ namespace dory {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 16;   // 34 KB of LDS per workgroup -> 4 workgroups per CU (BK = 32: 2 per CU, 7 % slower end to end)
+// k-tile depth is a template parameter of the kernels below; 16 everywhere: 34 KB of LDS per 128-wide workgroup -> 4
+// workgroups per CU (with 32 only 2 fit and the MFMA-bound 602->128 GEMMs run 7 % slower); the HBM-bound 64-wide
+// GEMMs of an Amazon-sized partition measured the same or a few per cent better with 16 than with 32
+constexpr int BK_SPLIT = 32;   // granularity of the split-K plan
 
 // A (BK x BT) operand tile travels global -> registers -> LDS (k-major).  The two halves
 // are separate so that the loads of tile t+1 are in flight while tile t is multiplied.
 // kmajor source: elem(k,i) = p[k*ld+i]; otherwise elem(k,i) = p[i*ld+k] (transposing copy).
-template <int BT, bool KMAJOR>
+template <int BT, bool KMAJOR, int BK>
 struct TileRegs {
     static constexpr int N4 = BT * BK / 4 / 256;   // float4 per thread
     float4 v[N4];
 };
 
-template <int BT, bool KMAJOR>
-__device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR> &r, const float *__restrict__ p, uint32_t ld,
+template <int BT, bool KMAJOR, int BK>
+__device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR, BK> &r, const float *__restrict__ p, uint32_t ld,
                                           uint32_t ext, uint32_t Kend, uint32_t i0, uint32_t k0) {
     const int t = threadIdx.x;
     if constexpr (KMAJOR) {
@@ -43,7 +46,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR> &r, const float *
         constexpr int KPI = 256 / VPR;       // k rows per iteration
         const int i4 = (t % VPR) * 4;
 #pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
             const uint32_t k = k0 + t / VPR + it * KPI;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < Kend) {
@@ -63,7 +66,7 @@ __device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR> &r, const float *
         constexpr int RPI = 256 / LPR;       // rows per iteration (32)
         const int kq = (t % LPR) * 4;
 #pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
             const uint32_t i = i0 + t / LPR + it * RPI;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < ext) {
@@ -81,22 +84,22 @@ __device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR> &r, const float *
     }
 }
 
-template <int BT, bool KMAJOR, int LLD>
-__device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR> &r) {
+template <int BT, bool KMAJOR, int LLD, int BK>
+__device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR, BK> &r) {
     const int t = threadIdx.x;
     if constexpr (KMAJOR) {
         constexpr int VPR = BT / 4;
         constexpr int KPI = 256 / VPR;
         const int i4 = (t % VPR) * 4;
 #pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it)
+        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it)
             *reinterpret_cast<float4 *>(lds + (t / VPR + it * KPI) * LLD + i4) = r.v[it];
     } else {
         constexpr int LPR = BK / 4;
         constexpr int RPI = 256 / LPR;
         const int kq = (t % LPR) * 4;
 #pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR>::N4; ++it) {
+        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
             const int rr = t / LPR + it * RPI;
             lds[(kq + 0) * LLD + rr] = r.v[it].x;
             lds[(kq + 1) * LLD + rr] = r.v[it].y;
@@ -106,17 +109,24 @@ __device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR
     }
 }
 
-template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
+// LDS geometry of one (BN, operand layouts, BK) instantiation.  Row-major operands are transposed on their way into
+// LDS: BK/4 k-lanes x 32/(BK/4) rows per 32-lane group write (kq + c) * LD + rr, so the row pitch is chosen to keep
+// the 32 banks distinct: LD = 2 (mod 32) for BK = 16 (kq in {0,4,8,12}, rr in 0..7), LD = 1 (mod 32) for BK = 32.
+template <int BN, bool A_KMAJOR, bool B_KMAJOR, int BK>
+struct GemmLds {
+    static constexpr int TPAD = BK == 16 ? 2 : 1;
+    static constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + TPAD;
+    static constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + TPAD;
+    static constexpr int A_SZ = (BK * LDA_S + 3) & ~3;
+    static constexpr int B_SZ = (BK * LDB_S + 3) & ~3;
+    static constexpr int FLOATS = 2 * (A_SZ + B_SZ);   // two buffers per operand: tile t+1 is written while nobody reads it
+};
+
+template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, float *partial, float *smem) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    // row-major operands are transposed on their way into LDS: 4 k-lanes x 8 rows per 32-lane group write
-    // (kq + c) * LD + rr with kq in {0,4,8,12}, rr in 0..7 -> LD = 2 (mod 32) keeps the 32 banks distinct
-    constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + 2;
-    constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + 2;
-    constexpr int A_SZ = (BK * LDA_S + 3) & ~3;
-    constexpr int B_SZ = (BK * LDB_S + 3) & ~3;
-    // two LDS buffers per operand: tile t+1 is written while nobody reads it, one barrier per tile
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    using Lds = GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>;
+    constexpr int LDA_S = Lds::LDA_S, LDB_S = Lds::LDB_S, A_SZ = Lds::A_SZ, B_SZ = Lds::B_SZ;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -136,21 +146,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     const int fr = lane & 31;   // row/col inside the 32-wide fragment
     const int fk = lane >> 5;   // k offset inside the 2-deep MFMA
-    TileRegs<BM, A_KMAJOR> ra;
-    TileRegs<BN, B_KMAJOR> rb;
+    TileRegs<BM, A_KMAJOR, BK> ra;
+    TileRegs<BN, B_KMAJOR, BK> rb;
     int cur = 0;
     if (kbeg < kend) {
-        tile_load<BM, A_KMAJOR>(ra, g.A, g.lda, g.M, kend, i0, kbeg);
-        tile_load<BN, B_KMAJOR>(rb, g.B, g.ldb, g.N, kend, j0, kbeg);
-        tile_store<BM, A_KMAJOR, LDA_S>(smem, ra);
-        tile_store<BN, B_KMAJOR, LDB_S>(smem + A_SZ, rb);
+        tile_load<BM, A_KMAJOR, BK>(ra, g.A, g.lda, g.M, kend, i0, kbeg);
+        tile_load<BN, B_KMAJOR, BK>(rb, g.B, g.ldb, g.N, kend, j0, kbeg);
+        tile_store<BM, A_KMAJOR, LDA_S, BK>(smem, ra);
+        tile_store<BN, B_KMAJOR, LDB_S, BK>(smem + A_SZ, rb);
     }
     __syncthreads();
     for (uint32_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {  // next tile: global -> registers, in flight during the MFMAs below
-            tile_load<BM, A_KMAJOR>(ra, g.A, g.lda, g.M, kend, i0, k0 + BK);
-            tile_load<BN, B_KMAJOR>(rb, g.B, g.ldb, g.N, kend, j0, k0 + BK);
+            tile_load<BM, A_KMAJOR, BK>(ra, g.A, g.lda, g.M, kend, i0, k0 + BK);
+            tile_load<BN, B_KMAJOR, BK>(rb, g.B, g.ldb, g.N, kend, j0, k0 + BK);
         }
         const float *As = smem + cur * (A_SZ + B_SZ);
         const float *Bs = As + A_SZ;
@@ -169,8 +179,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         if (more) {
             float *An = smem + (cur ^ 1) * (A_SZ + B_SZ);
-            tile_store<BM, A_KMAJOR, LDA_S>(An, ra);
-            tile_store<BN, B_KMAJOR, LDB_S>(An + A_SZ, rb);
+            tile_store<BM, A_KMAJOR, LDA_S, BK>(An, ra);
+            tile_store<BN, B_KMAJOR, LDB_S, BK>(An + A_SZ, rb);
         }
         __syncthreads();
         cur ^= 1;
@@ -195,6 +205,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
+}
+
+// 64-wide tiles: the registers fit six waves per SIMD without a hint
+template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>::FLOATS];
+    gemm_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
+}
+// 128-wide tiles with BK = 16: 34 KB of LDS -> four workgroups per CU if the kernel stays within 128 registers
+template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel_occ4(GemmArgs g, uint32_t klen,
+                                                                                                 float *partial) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>::FLOATS];
+    gemm_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
 }
 
 // second stage of split-K: C = sum_z partial[z] in z order (deterministic); eight
@@ -226,9 +250,9 @@ static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
     if (tiles == 0) return 1;
     // a workgroup walks its k-tiles one after the other (~1.9 us each): with few tiles even a
     // Cora-sized K (2 708 rows -> 85 k-tiles = 160 us on one workgroup) wants to be split
-    if (tiles >= 512 || K < 8 * BK) return 1;
-    uint32_t s = (512 + tiles - 1) / tiles;             // aim at ~512 workgroups = 256 CUs x 2 resident blocks
-    const uint32_t maxs = (K + 4 * BK - 1) / (4 * BK);  // at least 4 k-tiles per split
+    if (tiles >= 512 || K < 8 * BK_SPLIT) return 1;
+    uint32_t s = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups = 256 CUs x 4 resident blocks
+    const uint32_t maxs = (K + 4 * BK_SPLIT - 1) / (4 * BK_SPLIT);  // at least 128 k-rows per split
     if (s > maxs) s = maxs;
     if (s > 512) s = 512;
     return s < 1 ? 1 : s;
@@ -240,7 +264,7 @@ size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K) {
     return S > 1 ? (size_t)S * M * pad_ld(N) * sizeof(float) : 0;
 }
 
-template <int BN, int WM, int WN, int TM, int TN>
+template <int BN, int WM, int WN, int TM, int TN, int BK>
 static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
     if (g.K == 0) {   // empty partition: the product of an M x 0 and a 0 x N matrix is all zeros (tanh(0) = 0 too)
         hipError_t e = hipMemsetAsync(g.C, 0, (size_t)g.M * g.ldc * sizeof(float), s);
@@ -258,14 +282,18 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
     S = (g.K + klen - 1) / klen;
     dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, S);
     dim3 block(256);
-    if (!g.ta && !g.tb)
-        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, false, true>), grid, block, 0, s, g, klen, scratch);
-    else if (!g.ta && g.tb)
-        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, false, false>), grid, block, 0, s, g, klen, scratch);
-    else if (g.ta && !g.tb)
-        hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, true, true>), grid, block, 0, s, g, klen, scratch);
-    else
-        return hipErrorInvalidValue;
+#define GEMM_LAUNCH(AK, BKM)                                                                                              \
+    do {                                                                                                                  \
+        if constexpr (BN == 128)                                                                                          \
+            hipLaunchKernelGGL((gemm_kernel_occ4<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch);      \
+    } while (0)
+    if (!g.ta && !g.tb) GEMM_LAUNCH(false, true);
+    else if (!g.ta && g.tb) GEMM_LAUNCH(false, false);
+    else if (g.ta && !g.tb) GEMM_LAUNCH(true, true);
+    else return hipErrorInvalidValue;
+#undef GEMM_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (S > 1) {
@@ -281,8 +309,8 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
 
 hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
     if (g.M == 0 || g.N == 0) return hipSuccess;
-    if (g.N > 64) return launch_bn<128, 2, 2, 2, 2>(g, scratch, scratch_bytes, s);
-    return launch_bn<64, 4, 1, 1, 2>(g, scratch, scratch_bytes, s);
+    if (g.N > 64) return launch_bn<128, 2, 2, 2, 2, 16>(g, scratch, scratch_bytes, s);
+    return launch_bn<64, 4, 1, 1, 2, 16>(g, scratch, scratch_bytes, s);
 }
 
 }  // namespace dory
