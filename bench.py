@@ -126,6 +126,7 @@ def main():
                     "halo exchange skipped (per-rank compute time of an N-GPU run; diagnostic, not the metric)")
     ap.add_argument("--opt", nargs="*", default=[], help="context options key=value (diagnostic runs, e.g. spmm_variant=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra transform-first epochs (profiling runs: only the headline kernels)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows sampled for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
@@ -277,7 +278,7 @@ def main():
 
     # ---- the same epoch in the transform-first order of layer 0 (opt-in mode, reported beside the headline) ----
     alt = None
-    if world == 1 and not gat and not tf_mode and not args.emulate and not args.opt:
+    if world == 1 and not gat and not tf_mode and not args.emulate and not args.opt and not args.no_alt:
         ctx.set_option("gcn_transform_first", 2)
         if ctx.transform_first_active():
             ctx.timing_enable(False)

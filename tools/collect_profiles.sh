@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates the measurement evidence kept under profiles/ on a GPU box (run from the repo root):
+#   tools/collect_profiles.sh <tag>        e.g.  gpurun --timeout 1500 -- 'tools/collect_profiles.sh r02'
+# Writes gpurun_out/<tag>_*: the bench.py line, the rocprofv3 kernel summary of the same command, and the
+# FETCH_SIZE / WRITE_SIZE counter passes (each in its own run, kernel trace only, as MI355X_MICROARCH.md asks).
+set -u
+TAG=${1:-rXX}
+R=$PWD
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_k -o k -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_k.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_k -name '*.db' | head -1)" > "$OUT/${TAG}_bench_kernel_stats.txt" 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace -d /tmp/prof_${TAG}_$ctr -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_$ctr.log 2>&1
+    python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_$ctr -name '*.db' | head -1)" > "$OUT/${TAG}_pmc_$(echo $ctr | tr A-Z a-z).txt" 2>&1
+done
+cd "$R"
+python bench.py --gnn gat --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gat.json" 2>/dev/null
+python bench.py --gnn gatmh --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gatmh.json" 2>/dev/null
+python tools/bench_small.py > "$OUT/${TAG}_bench_small.txt" 2>/dev/null
+ls -la "$OUT" | grep "${TAG}_"
