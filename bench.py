@@ -50,6 +50,12 @@ def synth_edges(kind, V, E, seed=42):
         perm = rng.permutation(V).astype(np.uint32)
         s = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
         d = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
+    elif kind == "hub":
+        # uniform, plus one vertex that is an endpoint of 1 % of all edges (degree ~1.1 M: 50x real Reddit's maximum):
+        # the stress case for anything that walks a row's edge list on one lane group
+        s = rng.integers(0, V, half, dtype=np.uint32)
+        d = rng.integers(0, V, half, dtype=np.uint32)
+        d[rng.random(half) < 0.01] = 12345
     elif kind == "community":
         # 50 equal communities of consecutive ids (what a METIS-ordered Reddit looks like to the
         # kernels: subreddits): 85 % of the edges stay inside the source's community
@@ -115,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "community"])
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "community", "hub"])
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
     ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS),
                     help="graph/model shape; anything but reddit is a scale test, not the BASELINE metric line")

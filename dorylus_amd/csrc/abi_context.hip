@@ -177,6 +177,12 @@ static void free_graph(dory_ctx *c) {
     c->rowIdx = c->colIdx = nullptr;
     c->cscVal = c->csrVal = c->norm = nullptr;
     c->orderIn = c->orderOut = nullptr;
+    for (LongRowsDev *L : {&c->longIn, &c->longOut}) {
+        if (L->rows) (void)hipFree(L->rows);
+        if (L->row_chunk_ptr) (void)hipFree(L->row_chunk_ptr);
+        if (L->chunks) (void)hipFree(L->chunks);
+        *L = LongRowsDev{};
+    }
     free_blocked(&c->blkIn);
     free_blocked(&c->blkOut);
     c->blkIn_built = c->blkOut_built = false;
@@ -304,6 +310,17 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
     if ((rc = upload_array(c, &c->orderIn, oi.data(), (uint64_t)N))) return rc;
     if ((rc = upload_array(c, &c->orderOut, oo.data(), (uint64_t)N))) return rc;
+    for (int d = 0; d < 2; ++d) {   // K1's hub rows (spmm.hip: long rows)
+        LongRowsHost h;
+        plan_long_rows(d == 0 ? column_ptrs : row_ptrs, N, &h);
+        LongRowsDev &L = d == 0 ? c->longIn : c->longOut;
+        L.nrows = (uint32_t)h.rows.size();
+        L.nchunks = (uint32_t)(h.chunks.size() / 6);
+        if (!L.nchunks) continue;
+        if ((rc = upload_array(c, &L.rows, h.rows.data(), h.rows.size()))) return rc;
+        if ((rc = upload_array(c, &L.row_chunk_ptr, h.row_chunk_ptr.data(), h.row_chunk_ptr.size()))) return rc;
+        if ((rc = upload_array(c, &L.chunks, h.chunks.data(), h.chunks.size()))) return rc;
+    }
     c->has_graph = true;
     return DORY_OK;
 }

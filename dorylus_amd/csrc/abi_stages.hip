@@ -102,8 +102,15 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         int rc = wait_halo(c);
         if (rc) return rc;
     }
+    const LongRowsDev &longRows = csc ? c->longIn : c->longOut;
+    if (longRows.nchunks) {   // hubs: K1 stops after LONG_ROW_CLAMP edges of a row, workgroup-per-chunk kernels do the rest
+        int rc = ensure_scratch(c, (size_t)longRows.nchunks * a.ld * sizeof(float));
+        if (rc) return rc;
+        a.row_clamp = LONG_ROW_CLAMP;
+    }
     Timed t(c, "spmm", c->compute);
     HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+    if (longRows.nchunks) HIPCK(c, launch_spmm_long_rows(a, longRows, c->scratch, c->compute));
     return DORY_OK;
 }
 

@@ -51,6 +51,17 @@ struct BlockedAdj {
     uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order
     float *bval = nullptr;      // nnz
 };
+// K1's long rows (hubs): the part of a row beyond LONG_ROW_CLAMP edges, in chunks of LONG_ROW_CHUNK edges
+constexpr uint32_t LONG_ROW_CLAMP = 8192, LONG_ROW_CHUNK = 4096;
+struct LongRowsHost {                    // plan_long_rows output
+    std::vector<uint32_t> rows;          // long rows
+    std::vector<uint32_t> row_chunk_ptr; // rows+1: first chunk of each
+    std::vector<uint32_t> chunks;        // 6 words per chunk: row, 0, e0 (lo, hi), e1 (lo, hi)  (= struct LongChunk)
+};
+struct LongRowsDev {
+    uint32_t nrows = 0, nchunks = 0;
+    uint32_t *rows = nullptr, *row_chunk_ptr = nullptr, *chunks = nullptr;
+};
 struct AdamState {
     float lr = 0.01f;
     unsigned epochs = 1;  // AdamOptimizer ctor calls nextIteration() once
@@ -85,6 +96,7 @@ struct dory_ctx {
     float *cscVal = nullptr, *csrVal = nullptr, *norm = nullptr;
     // longest-row-first schedules for the SpMM (built at upload)
     uint32_t *orderIn = nullptr, *orderOut = nullptr;
+    dory::LongRowsDev longIn, longOut;          // K1: hub rows of forwardAdj / backwardAdj
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
     bool blkIn_built = false, blkOut_built = false;
@@ -152,9 +164,13 @@ struct SpmmArgs {
     const float *xg;        // G x ld (may be nullptr when no ghosts)
     float *out;             // N x ld
     int accumulate;         // 1: out += result (GAT backward second pass)
+    uint32_t row_clamp;     // K1: edges of a row beyond this many are left to the long-row kernels (0 = no limit)
     const uint32_t *order;  // optional row schedule (longest first) or nullptr
 };
 hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);
+
+void plan_long_rows(const uint64_t *ptr, uint32_t N, LongRowsHost *out);
+hipError_t launch_spmm_long_rows(const SpmmArgs &a, const LongRowsDev &L, float *partial /*nchunks x ld*/, hipStream_t s);
 
 hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                          uint64_t nnz, uint32_t want_nb /*0 = auto*/, uint32_t row_bytes, BlockedAdj *out,

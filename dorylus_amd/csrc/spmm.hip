@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     }
 
     uint64_t e = row_ok ? a.ptr[v] : 0;
-    const uint64_t end = row_ok ? a.ptr[v + 1] : 0;
+    uint64_t end = row_ok ? a.ptr[v + 1] : 0;
+    if (a.row_clamp && end - e > a.row_clamp) end = e + a.row_clamp;   // the rest of a long row: spmm_longrow_kernel
     // GROUP == 64: the loop is wave-uniform (one row per wave).
     while (e < end) {
         const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
@@ -154,6 +155,102 @@ static hipError_t launch_t(const SpmmArgs &a, hipStream_t s) {
     dim3 grid((a.N + RPB - 1) / RPB, (nchunk + GROUP * CHUNKS - 1) / (GROUP * CHUNKS));
     if (a.N == 0 || nchunk == 0) return hipSuccess;
     hipLaunchKernelGGL((spmm_rows_kernel<GROUP, CHUNKS>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- long rows ---------------------------------------------------------------------------------------
+// K1 walks a row's edge list on one lane group: a hub (a vertex with 1 % of all edges costs 300 ms at Reddit scale)
+// would serialise the launch.  Rows longer than LONG_ROW_CLAMP edges are therefore cut: K1 does the self term and
+// the first LONG_ROW_CLAMP edges, the remainder is split into chunks of LONG_ROW_CHUNK edges, one workgroup each
+// (4 waves x a contiguous quarter of the chunk, whole row width per wave, wave partials added in wave order through
+// LDS), and a last kernel adds a row's chunk sums to `out` in chunk order -- deterministic, no atomics.
+struct LongChunk { uint32_t row; uint32_t pad; uint64_t e0, e1; };
+
+__global__ __launch_bounds__(256) void spmm_longrow_kernel(SpmmArgs a, const LongChunk *chunks, float *partial) {
+    extern __shared__ float4 lds4[];                    // [4][nchunk]
+    const LongChunk ch = chunks[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nchunk = a.ld >> 2;
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
+    const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg);
+    const uint64_t len = ch.e1 - ch.e0, q = (len + 3) / 4;
+    const uint64_t wb = ch.e0 + (uint64_t)wave * q, we = wb + q < ch.e1 ? wb + q : ch.e1;
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += 64) {      // 256 floats of the row per pass
+        const uint32_t col = c0 + lane;
+        const bool act = col < nchunk;
+        const uint32_t cc = act ? col : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint64_t e = wb;
+        for (; e + 4 <= we; e += 4) {
+            float4 x[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t s = a.idx[e + u];        // wave-uniform
+                w[u] = a.val[e + u];
+                x[u] = (s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk)[cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fma4(w[u], x[u], acc);
+        }
+        for (; e < we; ++e) {
+            const uint32_t s = a.idx[e];
+            acc = fma4(a.val[e], (s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk)[cc], acc);
+        }
+        if (act) lds4[(size_t)wave * nchunk + col] = acc;
+    }
+    __syncthreads();
+    float4 *p4 = reinterpret_cast<float4 *>(partial) + (size_t)blockIdx.x * nchunk;
+    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+        float4 r = lds4[col];
+        for (int w = 1; w < 4; ++w) {
+            const float4 t = lds4[(size_t)w * nchunk + col];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        p4[col] = r;
+    }
+}
+
+// out[row,:] += sum of the row's chunk partials, in chunk order (one workgroup per long row)
+__global__ __launch_bounds__(256) void spmm_longrow_reduce_kernel(SpmmArgs a, const uint32_t *row_ids,
+                                                                  const uint32_t *row_chunk_ptr, const float *partial) {
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t r = row_ids[blockIdx.x], c_beg = row_chunk_ptr[blockIdx.x], c_end = row_chunk_ptr[blockIdx.x + 1];
+    const float4 *p4 = reinterpret_cast<const float4 *>(partial);
+    float4 *out4 = reinterpret_cast<float4 *>(a.out) + (size_t)r * nchunk;
+    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+        float4 acc = out4[col];
+        for (uint32_t c = c_beg; c < c_end; ++c) {
+            const float4 t = p4[(size_t)c * nchunk + col];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        out4[col] = acc;
+    }
+}
+
+void plan_long_rows(const uint64_t *ptr, uint32_t N, LongRowsHost *out) {
+    out->rows.clear(); out->row_chunk_ptr.assign(1, 0); out->chunks.clear();
+    for (uint32_t v = 0; v < N; ++v) {
+        const uint64_t beg = ptr[v], end = ptr[v + 1];
+        if (end - beg <= LONG_ROW_CLAMP) continue;
+        out->rows.push_back(v);
+        for (uint64_t e = beg + LONG_ROW_CLAMP; e < end; e += LONG_ROW_CHUNK) {
+            out->chunks.push_back(v);                                  // row
+            out->chunks.push_back(0);
+            const uint64_t e1 = e + LONG_ROW_CHUNK < end ? e + LONG_ROW_CHUNK : end;
+            out->chunks.push_back((uint32_t)(e & 0xFFFFFFFFu)); out->chunks.push_back((uint32_t)(e >> 32));
+            out->chunks.push_back((uint32_t)(e1 & 0xFFFFFFFFu)); out->chunks.push_back((uint32_t)(e1 >> 32));
+        }
+        out->row_chunk_ptr.push_back((uint32_t)(out->chunks.size() / 6));
+    }
+}
+
+hipError_t launch_spmm_long_rows(const SpmmArgs &a, const LongRowsDev &L, float *partial, hipStream_t s) {
+    if (L.nchunks == 0 || a.ld == 0) return hipSuccess;
+    const uint32_t nchunk = a.ld >> 2;
+    hipLaunchKernelGGL(spmm_longrow_kernel, dim3(L.nchunks), dim3(256), (size_t)4 * nchunk * sizeof(float4), s, a,
+                       reinterpret_cast<const LongChunk *>(L.chunks), partial);
+    hipLaunchKernelGGL(spmm_longrow_reduce_kernel, dim3(L.nrows), dim3(256), 0, s, a, L.rows, L.row_chunk_ptr, partial);
     return hipGetLastError();
 }
 

@@ -115,6 +115,40 @@ def test_blocked_variant_many_blocks(da):
     ctx.close()
 
 
+def test_k1_hub_rows_are_split(da):
+    """K1 (row gather) with rows far beyond LONG_ROW_CLAMP = 8192 edges: the clamped main launch plus the
+    workgroup-per-chunk kernels give the oracle's aggregate, forward and backward, several widths."""
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    rng = np.random.default_rng(21)
+    V, E = 3000, 120000
+    s = rng.integers(0, V, E)
+    d = rng.integers(0, V, E)
+    d[:40000] = 7            # hub destination: in-degree ~40k (5 chunks beyond the clamp, last one ragged)
+    s[40000:70000] = 11      # hub source: out-degree ~30k
+    d[70000:79000] = 13      # just above the clamp: one short chunk
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    assert np.diff(g["colPtr"].astype(np.int64)).max() > 8192 and np.diff(g["rowPtr"].astype(np.int64)).max() > 8192
+    for F in (16, 128, 602):
+        ctx = make_ctx(da, g, [F, F, 3], V)
+        ctx.set_option("spmm_variant", 0)
+        x = rng.standard_normal((V, F)).astype(np.float32)
+        gr = rng.standard_normal((V, F)).astype(np.float32)
+        ctx.upload(0, "x", x)
+        ctx.upload(1, "grad", gr)
+        for slab in (0, 64):
+            ctx.set_option("spmm_slab", slab)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
+            ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr)
+            # 30-40k-term sums in chunk order instead of edge order: the 1e-4 bar of the path, not the 1e-5 of short rows
+            assert rel_err(ctx.download(0, "ah"), ref_f) < RTOL, (F, slab)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < RTOL, (F, slab)
+        ctx.close()
+
+
 @pytest.mark.parametrize("slab", [0, 32, 64, 128, 256])
 def test_aggregate_feature_slabs(da, slab):
     import orc
