@@ -105,9 +105,11 @@ def oracle_gcn_epoch(gs, parts, X, labels, Ws, globalV):
     return T, dW
 
 
-def make_ctx(da, g, dims, globalV, gnn=0, node_id=0, num_nodes=1, device=0):
+def make_ctx(da, g, dims, globalV, gnn=0, node_id=0, num_nodes=1, device=0, options=None):
     ctx = da.Context(device)
     ctx.configure(gnn, dims, globalV, node_id, num_nodes)
+    for k, v in (options or {}).items():      # before preallocate: e.g. spmm_blk_nb forces the blocked kernels on toy graphs
+        ctx.set_option(k, v)
     ctx.graph_upload(g)
     ctx.preallocate()
     return ctx

@@ -518,8 +518,10 @@ def test_engine_epoch_matches_manual_order(da):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("case,dims", [("parts_toy60_p1", [9, 6, 4]), ("parts_toy60_p2", [30, 16, 5])])
-def test_gat_stages_vs_oracle(da, case, dims):
+@pytest.mark.parametrize("nb", [0, 8])   # 8: force the source-blocked unit-weight path (toy graphs otherwise take K1)
+@pytest.mark.parametrize("case,dims", [("parts_toy60_p1", [9, 6, 4]), ("parts_toy60_p2", [30, 16, 5]),
+                                       ("parts_toy60_p2", [30, 64, 5])])
+def test_gat_stages_vs_oracle(da, case, dims, nb):
     """K5 + GAT aggregate forward/backward (parity vs reference unpinned; oracle = restatement)."""
     import orc
     from helpers import make_ctx, rel_err
@@ -527,7 +529,8 @@ def test_gat_stages_vs_oracle(da, case, dims):
     rng = np.random.default_rng(11)
     for r, g in enumerate(gs):
         N, E = g["localVtxCnt"], g["localInEdgeCnt"]
-        ctx = make_ctx(da, g, dims, g["globalVtxCnt"], gnn=da.GAT, node_id=r, num_nodes=len(gs))
+        ctx = make_ctx(da, g, dims, g["globalVtxCnt"], gnn=da.GAT, node_id=r, num_nodes=len(gs),
+                       options={"spmm_blk_nb": nb})
         F = dims[1]
         h = rng.uniform(-1, 1, (N, dims[0])).astype(np.float32)
         W = (rng.standard_normal((dims[0], F)) / 3).astype(np.float32)
@@ -567,7 +570,8 @@ def test_gat_stages_vs_oracle(da, case, dims):
         ctx.close()
 
 
-def test_gat_engine_epoch_vs_oracle(da):
+@pytest.mark.parametrize("nb", [0, 8])
+def test_gat_engine_epoch_vs_oracle(da, nb):
     """Whole GAT epoch through the C++ Engine (stage order of pipeline.cpp for GAT) == oracle."""
     import orc
     import partition_oracle as po
@@ -580,7 +584,7 @@ def test_gat_engine_epoch_vs_oracle(da):
     labels = rng.integers(0, dims[-1], V).astype(np.uint32)
     Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
     As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(2)]
-    ctx = make_ctx(da, g, dims, V, gnn=da.GAT)
+    ctx = make_ctx(da, g, dims, V, gnn=da.GAT, options={"spmm_blk_nb": nb})
     ctx.upload(0, "h", H0)
     ctx.labels_upload(labels)
     for l in range(2):
