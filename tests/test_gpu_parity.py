@@ -170,7 +170,7 @@ def test_aggregate_feature_slabs(da, slab):
     ctx.close()
 
 
-def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None, transform_first=0):
+def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, native_plan=None, transform_first=0, blk_nb=0):
     """P partitions as P contexts on one GPU; the transport between them is a host
     copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
     import torch
@@ -180,7 +180,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
     V = int(gs[0]["globalVtxCnt"])
     ctxs, engs, plans = [], [], []
     for r, g in enumerate(gs):
-        ctx = make_ctx(da, g, dims, V, node_id=r, num_nodes=P)
+        ctx = make_ctx(da, g, dims, V, node_id=r, num_nodes=P, options={"spmm_blk_nb": blk_nb})
         ctx.upload(0, "x", X[g["localToGlobal"]])
         ctx.upload(0, "fg", X[g["srcGhost"]].reshape(g["srcGhostCnt"], dims[0]))
         ctx.labels_upload(labels[g["localToGlobal"]])
@@ -261,7 +261,8 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
     ("parts_toy97_p8_und", [300, 64, 64, 25]),     # BASELINE config 4 shape: Amazon GCN 3-layer, 8 partitions
     ("parts_toy97_p8_und", [256, 48, 51]),         # BASELINE config 5 shape: Friendster GCN 2-layer, 8 partitions
 ])
-def test_gcn_epoch_vs_oracle(da, case, dims):
+@pytest.mark.parametrize("blk_nb", [0, 8])   # 8: the source-blocked K1b kernels even on these L2-sized graphs
+def test_gcn_epoch_vs_oracle(da, case, dims, blk_nb):
     """Whole forward+backward epoch, every named tensor, P partitions with halo."""
     from helpers import oracle_gcn_epoch, rel_err
     gs, parts = _golden_partitions(case)
@@ -271,7 +272,7 @@ def test_gcn_epoch_vs_oracle(da, case, dims):
     labels = rng.integers(0, dims[-1], V).astype(np.uint32)
     Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)
           for i in range(len(dims) - 1)]
-    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws)
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, blk_nb=blk_nb)
     T, dW = oracle_gcn_epoch(gs, parts, X, labels, Ws, V)
     L = len(dims) - 1
     for r, c in enumerate(ctxs):
@@ -332,7 +333,7 @@ def test_gcn_epoch_transform_first_vs_oracle(da, case, dims, mode):
     labels = rng.integers(0, dims[-1], V).astype(np.uint32)
     Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)
           for i in range(len(dims) - 1)]
-    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, transform_first=mode)
+    ctxs, dWs, stats = _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, transform_first=mode, blk_nb=8 if mode == 2 else 0)
     assert ctxs[0].transform_first_active()
     tfl = [ctxs[0].transform_first_layer(l) for l in range(len(dims) - 1)]
     assert tfl[0] and (mode == 2 or not any(tfl[1:]))
