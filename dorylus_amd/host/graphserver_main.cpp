@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
     if (args.count("help") || !lookup(args, "datasetdir", &datasetDir) || !lookup(args, "featuresfile", &featuresFile) ||
         !lookup(args, "layerfile", &layerFile) || !lookup(args, "labelsfile", &labelsFile)) {
         fprintf(stderr, "usage: graphserver --datasetdir D/ --featuresfile F --layerfile L --labelsfile Y "
-                        "[--numEpochs N] [--gnn GCN|GAT] [--undirected 0|1] [--tmpdir T] [--lr 0.01] "
+                        "[--numEpochs N] [--gnn GCN|GAT] [--undirected 0|1] [--tmpdir T] [--lr 0.01] [--dory-<option> <int>] "
                         "[reference flags are accepted]\n");
         return 2;
     }
@@ -171,6 +171,9 @@ int main(int argc, char **argv) {
     if (dory_create(localRank, &ctx)) DIE("%s", dory_last_error(nullptr));
 #define CK(call) if (call) DIE("%s: %s", #call, dory_last_error(ctx))
     CK(dory_configure(ctx, gat ? DORY_GAT : DORY_GCN, L, dims, v.global_vtx_cnt, nodeId, numNodes));
+    // library options that have no reference flag: --dory-<option> <integer>, e.g. --dory-gcn_transform_first 2
+    for (auto &kv : args)
+        if (kv.first.rfind("dory-", 0) == 0) CK(dory_set_option(ctx, kv.first.substr(5).c_str(), atoll(kv.second.c_str())));
     CK(dory_partition_upload(ctx, part, numNodes > 1 ? parts.data() : nullptr));
     CK(dory_preallocate(ctx));
     CK(dory_tensor_upload(ctx, 0, gat ? "h" : "x", x.data()));

@@ -60,3 +60,11 @@ def test_graphserver_cora_shaped(tmp_path):
     T, _ = oracle_gcn_epoch([g], np.zeros(V, np.int64), X, y, Ws, V)
     nval = int(V * 0.1)
     assert abs(losses[0] - T[0]["loss"] / nval) < 1e-4 * max(1.0, T[0]["loss"] / nval)
+    # library options without a reference flag pass through as --dory-<option>: the transform-first order gives the
+    # same training curve within fp32 rounding, an unknown option is refused
+    r2 = subprocess.run(cmd + ["--dory-gcn_transform_first", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    losses2 = [float(m.group(2)) for m in re.finditer(r"batch Acc: ([0-9.]+), Loss: ([0-9.]+)", r2.stderr)]
+    assert len(losses2) == 4 and np.allclose(losses2, losses, rtol=2e-4)
+    r3 = subprocess.run(cmd + ["--dory-no_such_option", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r3.returncode != 0 and "unknown option" in r3.stderr
