@@ -58,12 +58,13 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7u;
     uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
+    const uint32_t tile_seq = q % tiles;
     q /= tiles;
     const uint32_t round = q % rounds;
     const uint32_t slab = q / rounds;
     const uint32_t b = round * 8u + xcd;
     if (b >= B.nb) return;
+    const uint32_t tile = (uint32_t)(((uint64_t)tile_seq + (uint64_t)b * B.SB / GATMH_BLK_ROWS) % tiles);   // own tiles first (spmm.hip)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % GROUP, gi = lane / GROUP;
     const uint32_t nchunk = a.ld >> 2;
@@ -194,12 +195,13 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7u;
     uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
+    const uint32_t tile_seq = q % tiles;
     q /= tiles;
     const uint32_t round = q % rounds;
     const uint32_t slab = q / rounds;
     const uint32_t b = round * 8u + xcd;
     if (b >= B.nb) return;
+    const uint32_t tile = (uint32_t)(((uint64_t)tile_seq + (uint64_t)b * B.SB / GATMH_BLK_ROWS) % tiles);   // own tiles first (spmm.hip)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % GROUP, gi = lane / GROUP;
     const uint32_t nchunk = a.ld >> 2;
@@ -295,12 +297,13 @@ __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a,
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7u;
     uint32_t q = id >> 3;
-    const uint32_t tile = q % tiles;
+    const uint32_t tile_seq = q % tiles;
     q /= tiles;
     const uint32_t round = q % rounds;
     const uint32_t slab = q / rounds;
     const uint32_t b = round * 8u + xcd;
     if (b >= B.nb) return;
+    const uint32_t tile = (uint32_t)(((uint64_t)tile_seq + (uint64_t)b * B.SB / GATMH_BLK_ROWS) % tiles);   // own tiles first (spmm.hip)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % GROUP, gi = lane / GROUP;
     const uint32_t nchunk = a.ld >> 2;

@@ -426,12 +426,16 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7u;
     uint32_t k = id >> 3;
-    const uint32_t tile = k % tiles;
+    const uint32_t tile_seq = k % tiles;
     k /= tiles;
     const uint32_t round = round0 + k % rounds;
     const uint32_t slab = k / rounds;
     const uint32_t b = round * 8u + xcd;
     if (b < b_lo || b >= b_hi) return;   // this launch covers source blocks [b_lo, b_hi)
+    // the tiles whose own rows lie in source block b go first: on a graph with locality (communities of consecutive
+    // ids) they hold most of the block's edges, and starting them last would leave the XCD waiting for a few long
+    // workgroups at the end of the round; on a graph without locality the rotation changes nothing
+    const uint32_t tile = (uint32_t)(((uint64_t)tile_seq + (uint64_t)b * B.SB / BLK_ROWS) % tiles);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
