@@ -20,7 +20,7 @@ SYMBOLS = [
     "dory_weight_set", "dory_weight_get", "dory_weight_grad_get", "dory_weights_init_xavier",
     "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
-    "dory_halo_unpack", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
+    "dory_halo_unpack", "dory_halo_pack_tensor", "dory_halo_unpack_tensor", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
     "dory_gatmh_heads", "dory_transform_first_active", "dory_transform_first_layer",
@@ -70,6 +70,8 @@ def load():
         "dory_halo_exchange": [vp, u32, i32],
         "dory_halo_pack": [vp, u32, i32, vp],
         "dory_halo_unpack": [vp, u32, i32, vp],
+        "dory_halo_pack_tensor": [vp, u32, cp, i32, vp],
+        "dory_halo_unpack_tensor": [vp, u32, cp, i32, vp],
         "dory_adam_config": [vp, f32],
         "dory_weight_update": [vp, u32],
         "dory_timing_enable": [vp, i32],
@@ -284,6 +286,12 @@ class Context:
 
     def halo_unpack(self, layer, direction, dev_ptr):
         self._ck(self.lib.dory_halo_unpack(self.h, layer, direction, C.c_void_p(dev_ptr)))
+
+    def halo_pack_tensor(self, layer, name, direction, dev_ptr):
+        self._ck(self.lib.dory_halo_pack_tensor(self.h, layer, name.encode(), direction, C.c_void_p(dev_ptr)))
+
+    def halo_unpack_tensor(self, layer, name, direction, dev_ptr):
+        self._ck(self.lib.dory_halo_unpack_tensor(self.h, layer, name.encode(), direction, C.c_void_p(dev_ptr)))
 
     # -- optimiser ---------------------------------------------------------------------------
     def adam_config(self, lr):

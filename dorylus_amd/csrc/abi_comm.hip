@@ -114,18 +114,18 @@ int dory_halo_unpack(dory_ctx *c, uint32_t layer, int dir, const float *recv_buf
     return DORY_OK;
 }
 
-int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
-    CHECK_CTX(c);
-    { int wrc = wait_halo(c); if (wrc) return wrc; }
-    if (c->numNodes == 1) return DORY_OK;  // no ghosts
-    if (c->gnn == DORY_GATMH) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only");
-    Tensor *src, *ghost;
-    int rc = halo_tensors(c, layer, dir, &src, &ghost);
-    if (rc) return rc;
+}  // extern "C"
+
+namespace dory {
+// One all-to-all-v of rows: src rows listed in plan[dir] -> the peers' ghost tensors.  pack -> grouped
+// ncclSend/ncclRecv -> unpack on the comm stream, ordered after the compute stream's work so far; the compute
+// stream waits for the ghosts at once (defer == false) or when wait_halo() is next called (halo_overlap).
+int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) {
     HaloPlan &p = c->plan[dir];
     if (!p.set) return fail(c, DORY_ERR_ARG, "halo_exchange: no plan");
     if (!c->nccl) return fail(c, DORY_ERR_COMM, "halo_exchange: dory_comm_init not called");
     if (c->nranks != (int)c->numNodes) return fail(c, DORY_ERR_COMM, "halo_exchange: communicator size != num_nodes");
+    if (src->ld != ghost->ld) return fail(c, DORY_ERR_ARG, "halo_exchange: row widths of source and ghost tensor differ");
     const uint32_t w = src->ld;  // padded row width travels (keeps 16-B lanes)
     const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
     if (sb > c->send_cap) {
@@ -160,11 +160,52 @@ int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
         NCCLCK(c, ncclGroupEnd());
         HIPCK(c, launch_scatter_rows(ghost->d, c->recv_buf, ghost->ld, w, p.d_recv_slots, p.recv_total, c->comm));
     }
-    // consumers on the compute stream wait for the ghosts: at once, or (halo_overlap) when
-    // the first of them needs the ghost rows -- see wait_halo()
     HIPCK(c, hipEventRecord(c->ev_b, c->comm));
-    if (c->opt["halo_overlap"]) c->halo_pending = true;
+    if (defer && c->opt["halo_overlap"]) c->halo_pending = true;
     else HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+    return DORY_OK;
+}
+}  // namespace dory
+
+extern "C" {
+
+int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (c->numNodes == 1) return DORY_OK;  // no ghosts
+    // multi-head extension: the backward sweep exchanges dO and its per-vertex statistics itself, between its two
+    // phases (dory_aggregate); the scatter stage of the reference's GAT order has nothing to ship before it
+    if (c->gnn == DORY_GATMH && dir == DORY_BACKWARD) return DORY_OK;
+    Tensor *src, *ghost;
+    int rc = halo_tensors(c, layer, dir, &src, &ghost);
+    if (rc) return rc;
+    // consumers on the compute stream wait for the ghosts at once, or (halo_overlap) when the first of them needs
+    // the ghost rows -- see wait_halo()
+    return exchange_rows(c, dir, src, ghost, true);
+}
+
+// pack / unpack of any named tensor with the plan of `dir` (foreign transports, multi-context tests)
+int dory_halo_pack_tensor(dory_ctx *c, uint32_t layer, const char *name, int dir, float *send_buf) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *src = name ? find(c, layer, name) : nullptr;
+    if (!src || (dir != 0 && dir != 1) || !c->plan[dir].set) return fail(c, DORY_ERR_ARG, "halo_pack_tensor: no tensor '%s'@%u or no plan", name ? name : "(null)", layer);
+    HaloPlan &p = c->plan[dir];
+    if (src->rows != c->N) return fail(c, DORY_ERR_ARG, "halo_pack_tensor: '%s' is not a per-local-vertex tensor", name);
+    Timed t(c, "halo", c->compute);
+    HIPCK(c, launch_gather_rows(send_buf, src->d, src->ld, src->ld, p.d_send_lvids, p.send_total, c->compute));
+    return DORY_OK;
+}
+
+int dory_halo_unpack_tensor(dory_ctx *c, uint32_t layer, const char *name, int dir, const float *recv_buf) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    Tensor *ghost = name ? find(c, layer, name) : nullptr;
+    if (!ghost || (dir != 0 && dir != 1) || !c->plan[dir].set) return fail(c, DORY_ERR_ARG, "halo_unpack_tensor: no tensor '%s'@%u or no plan", name ? name : "(null)", layer);
+    HaloPlan &p = c->plan[dir];
+    if (ghost->rows != (dir == DORY_FORWARD ? c->Gsrc : c->Gdst)) return fail(c, DORY_ERR_ARG, "halo_unpack_tensor: '%s' is not a ghost tensor of that direction", name);
+    Timed t(c, "halo", c->compute);
+    HIPCK(c, launch_scatter_rows(ghost->d, recv_buf, ghost->ld, ghost->ld, p.d_recv_slots, p.recv_total, c->compute));
     return DORY_OK;
 }
 

@@ -161,6 +161,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
+    c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
     c->opt["gcn_transform_first"] = 0;   // GCN layers as A(XW) instead of (AX)W where the input is wider than the output: 1 = layer 0, 2 = all (see tf_layer)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
@@ -365,7 +366,6 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "bgg", c->Gdst, d[l + 1]);   // ghost rows of g_l (backward exchange)
         }
     } else if (c->gnn == DORY_GATMH) {  // extension (no reference counterpart): see dory_gatmh_heads
-        if (c->numNodes > 1) return fail(c, DORY_ERR_ARG, "multi-head GAT extension: single partition only in this version");
         mk(0, "h", N, d[0]);
         mk(L - 1, "lab", N, d[L]);
         mk(L - 1, "logits", N, d[L]);
@@ -382,6 +382,14 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "do", N, zw);
             mk(l, "dz", N, zw);
             for (const char *nm : {"el", "er", "m", "den", "t", "del", "der"}) mk(l, nm, N, K);
+            mk(l, "st", N, 4 * K);               // (er, m, 1/den, t) per (v,k): what the source-side sweep gathers per edge
+            // partitioned runs: ghost sources of the in-edges (z exchanged forward, el/er recomputed from it) and
+            // ghost destinations of the out-edges (dO and st exchanged between the two phases of the backward sweep)
+            mk(l, "fg_z", c->Gsrc, zw);
+            mk(l, "fg_el", c->Gsrc, K);
+            mk(l, "fg_er", c->Gsrc, K);
+            mk(l, "bg_do", c->Gdst, zw);
+            mk(l, "bg_st", c->Gdst, 4 * K);
             if (!last) mk(l + 1, "h", N, d[l + 1]);
             if (l > 0) mk(l, "dh", N, d[l]);
         }

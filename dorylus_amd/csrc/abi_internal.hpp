@@ -92,6 +92,8 @@ int wait_halo(dory_ctx *c);
 // transform-first order applies to this GCN layer (option, model shape, adjacency values): see abi_context.hip
 bool tf_layer(dory_ctx *c, uint32_t layer);
 bool tf_active(dory_ctx *c);   // = tf_layer(c, 0)
+// one all-to-all-v of rows with the plan of `dir` (abi_comm.hip)
+int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer);
 // K1b bookkeeping (abi_stages.hip)
 int ensure_blocked(dory_ctx *c, bool csc, int group);
 int blk_group_for(dory_ctx *c, uint32_t ld);

@@ -25,7 +25,9 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u);
         // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
         // K1 then gathers from L2 without partial sums or a second kernel
-        const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20);
+        // (a partitioned multi-head GAT run has no row-wise form that reads ghost rows: it always takes the blocks)
+        const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20) &&
+                          !(c->gnn == DORY_GATMH && c->numNodes > 1);
         if (tiny || nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
             (csc ? c->blkIn_na : c->blkOut_na) = true;
             return DORY_OK;
@@ -175,9 +177,13 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 const bool blocked = c->opt["gatmh_blocked"] && c->blkIn_built && !c->blkIn_na && c->blkIn.nb > 0 &&
                                      (D % 4 == 0 || K == 1) &&
                                      (size_t)c->blkIn.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
+                NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el");
                 if (blocked)
                     HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->blkIn, z->d,
-                                                          el->d, er->d, o->d, m->d, den->d, c->partial, c->compute));
+                                                          fgz->d, el->d, fgel->d, er->d, o->d, m->d, den->d, c->partial,
+                                                          c->Gsrc > 0, c->compute));
+                else if (c->numNodes > 1)
+                    return fail(c, DORY_ERR_ARG, "multi-head GAT: a partitioned run needs the source-blocked kernels (gatmh_blocked = 1, K*D a shape they cover)");
                 else
                     HIPCK(c, launch_gatmh_forward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, z->d, el->d, er->d,
                                                   o->d, m->d, den->d, c->compute));
@@ -193,7 +199,9 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             return DORY_OK;
         }
         NEED(dO, fl, "do"); NEED(dz, fl, "dz"); NEED(tt, fl, "t"); NEED(del, fl, "del"); NEED(der, fl, "der");
-        {
+        NEED(st, fl, "st"); NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el"); NEED(bgdo, fl, "bg_do"); NEED(bgst, fl, "bg_st");
+        const int64_t phase = c->opt["gatmh_bwd_phase"];   // 0: whole sweep; 1 / 2: one phase (caller moves the ghost rows)
+        if (phase != 2) {
             Timed t(c, "loss", c->compute);
             if (last) {
                 NEED(gr, fl, "grad");
@@ -205,22 +213,35 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         }
         int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
-        Timed t(c, "spmm", c->compute);
         const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
         if (c->opt["gatmh_blocked"] && c->blkIn_built && c->blkOut_built && !c->blkIn_na && !c->blkOut_na && nbmax > 0 &&
             gatmh_backward_blocked_ok(K, D, z->ld) &&
-            (size_t)nbmax * c->N * (z->ld + K) * sizeof(float) <= c->partial_bytes &&
-            c->scratch_bytes >= (size_t)c->N * K * 16 + 256 + (size_t)z->cols * sizeof(float)) {
-            float4 *st4 = reinterpret_cast<float4 *>(c->scratch);
-            const size_t st4_bytes = ((size_t)c->N * K * 16 + 255) & ~(size_t)255;
-            HIPCK(c, launch_gatmh_backward_blocked(c->N, K, D, z->ld, el->ld, c->blkIn, c->blkOut, z->d, el->d, er->d, m->d,
-                                                   den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d, tt->d,
-                                                   del->d, der->d, dz->d, c->partial, st4, c->compute));
+            (size_t)nbmax * c->N * (z->ld + K) * sizeof(float) <= c->partial_bytes) {
+            float4 *st4 = reinterpret_cast<float4 *>(st->d);
+            const uint32_t lds4 = st->ld / 4;
+            if (phase != 2) {   // destination side: t, der, st
+                Timed t(c, "spmm", c->compute);
+                HIPCK(c, launch_gatmh_backward_blocked_dst(c->N, K, D, z->ld, el->ld, c->blkIn, z->d, fgz->d, el->d, fgel->d,
+                                                           er->d, m->d, den->d, dO->d, tt->d, der->d, c->partial, st4, lds4,
+                                                           c->Gsrc > 0, c->compute));
+            }
+            if (phase == 1) return DORY_OK;
+            if (phase == 0 && c->numNodes > 1) {   // ghost destinations of the out-edges: their dO and st rows
+                if ((rc = exchange_rows(c, DORY_BACKWARD, dO, bgdo, false))) return rc;
+                if ((rc = exchange_rows(c, DORY_BACKWARD, st, bgst, false))) return rc;
+            }
+            Timed t(c, "spmm", c->compute);
+            HIPCK(c, launch_gatmh_backward_blocked_src(c->N, K, D, z->ld, el->ld, c->blkOut, z->d, el->d, dO->d, bgdo->d, st4,
+                                                       reinterpret_cast<const float4 *>(bgst->d), lds4, der->d,
+                                                       c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d, del->d, dz->d,
+                                                       c->partial, c->Gdst > 0, c->compute));
             HIPCK(c, launch_gatmh_dattn(c->N, K, D, z->ld, el->ld, z->d, del->d, der->d, c->wgrads[fl]["a_l"].d,
-                                        c->wgrads[fl]["a_r"].d, c->scratch + st4_bytes / sizeof(float),
-                                        c->scratch_bytes - st4_bytes, c->compute));
+                                        c->wgrads[fl]["a_r"].d, c->scratch, c->scratch_bytes, c->compute));
             return DORY_OK;
         }
+        if (c->numNodes > 1)
+            return fail(c, DORY_ERR_ARG, "multi-head GAT: a partitioned run needs the source-blocked kernels (gatmh_blocked = 1, K*D a shape they cover)");
+        Timed t(c, "spmm", c->compute);
         HIPCK(c, launch_gatmh_backward(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->rowPtr, c->colIdx, z->d, el->d,
                                        er->d, m->d, den->d, dO->d, c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d,
                                        tt->d, del->d, der->d, dz->d, c->wgrads[fl]["a_l"].d, c->wgrads[fl]["a_r"].d,
@@ -360,6 +381,11 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
         Timed t(c, "edge", c->compute);
         HIPCK(c, launch_gatmh_scores(c->N, K, z->cols / K, z->d, z->ld, c->weights[l0]["a_l"].d, c->weights[l0]["a_r"].d,
                                      el->d, er->d, el->ld, c->compute));
+        if (c->Gsrc) {   // scores of the ghost sources from their exchanged z rows (el is all the in-edge side needs)
+            NEED(fgz, l0, "fg_z"); NEED(fgel, l0, "fg_el"); NEED(fger, l0, "fg_er");
+            HIPCK(c, launch_gatmh_scores(c->Gsrc, K, z->cols / K, fgz->d, fgz->ld, c->weights[l0]["a_l"].d,
+                                         c->weights[l0]["a_r"].d, fgel->d, fger->d, fgel->ld, c->compute));
+        }
         return DORY_OK;
     }
     const uint32_t fl = layer - 1;  // "layer--; // YIFAN: fix this" (CPU_comm.cpp:33)

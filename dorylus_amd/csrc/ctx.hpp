@@ -248,21 +248,29 @@ hipError_t launch_gatmh_forward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld,
 // source-blocked forward (statistics pass, weighted sum over K1b's blocked adjacency, reduce + self edge)
 hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
                                         const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
-                                        const float *z, const float *el, const float *er, float *o, float *m,
-                                        float *den, float *partial /*nb x N x ld*/, hipStream_t s);
+                                        const float *z, const float *zg /*ghost rows (ids >= N) or nullptr*/,
+                                        const float *el, const float *elg, const float *er, float *o, float *m,
+                                        float *den, float *partial /*nb x N x ld*/, bool ghosts, hipStream_t s);
+// source-blocked backward in two phases (a partitioned run exchanges the ghost rows of dO and st4 in between):
+// dst = t, der, st4 = (er, m, 1/den, t) per local (v,k); src = del, dz.  lds4: float4 stride of the st4 rows.
+bool gatmh_backward_blocked_ok(uint32_t K, uint32_t D, uint32_t ld);
+hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                             const BlockedAdj &Bin, const float *z, const float *zg, const float *el,
+                                             const float *elg, const float *er, const float *m, const float *den,
+                                             const float *d_o, float *t, float *der, float *partial, float4 *st4,
+                                             uint32_t lds4, bool ghosts, hipStream_t s);
+hipError_t launch_gatmh_backward_blocked_src(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                             const BlockedAdj &Bout, const float *z, const float *el, const float *d_o,
+                                             const float *dog, const float4 *st4, const float4 *stg, uint32_t lds4,
+                                             const float *der, const float *a_l, const float *a_r, float *del, float *dz,
+                                             float *partial /*nb x N x (ld + K) floats*/, bool ghosts, hipStream_t s);
+// row-wise backward (single partition; feature-per-lane or (edge, head, piece)-per-lane kernels by shape)
 hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                  const uint32_t *rowidx, const uint64_t *rowptr, const uint32_t *colidx,
                                  const float *z, const float *el, const float *er, const float *m, const float *den,
                                  const float *d_o, const float *a_l, const float *a_r, float *t, float *del,
                                  float *der, float *dz, float *da_l, float *da_r, float *scratch,
                                  size_t scratch_bytes, hipStream_t s);
-// source-blocked backward (needs both blocked adjacencies; see gatmh_backward_blocked_ok) and the a_l/a_r gradients
-bool gatmh_backward_blocked_ok(uint32_t K, uint32_t D, uint32_t ld);
-hipError_t launch_gatmh_backward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
-                                         const BlockedAdj &Bin, const BlockedAdj &Bout, const float *z, const float *el,
-                                         const float *er, const float *m, const float *den, const float *d_o,
-                                         const float *a_l, const float *a_r, float *t, float *del, float *der, float *dz,
-                                         float *partial /*max(nb) x N x (ld + K) floats*/, float4 *st4, hipStream_t s);
 hipError_t launch_gatmh_dattn(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const float *z,
                               const float *del, const float *der, float *da_l, float *da_r, float *scratch,
                               size_t scratch_bytes, hipStream_t s);

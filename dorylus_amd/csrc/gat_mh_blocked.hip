@@ -10,8 +10,9 @@ namespace dory {
 // over K1b's source-blocked adjacency -- workgroup id -> XCD id & 7, each XCD walks one 5 MB window of Z rows at a
 // time, alpha is recomputed per edge from el[src], er/m/den[dst] -- and a last kernel adds the partial rows and
 // the self edge.  Same mapping as spmm_blocked_kernel (spmm.hip): GROUP lanes x float4 = one slab of a row.
-__global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const float *el, const float *er, float *m_out,
-                                                          float *den_out) {
+template <bool GH>   // GH: ids >= N are ghost rows (partitioned run); without ghosts the select is compiled out
+__global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const float *el, const float *elg,
+                                                          const float *er, float *m_out, float *den_out) {
     const int lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= a.N) return;
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const flo
         const uint64_t e = e0 + j1;
         if (e <= e_end && kok) {
             const uint32_t u = e < e_end ? a.idx[e] : v;
-            const float s = lrelu02(el[(size_t)u * a.ldk + k1] + er_v);
+            const float el_u = (!GH || u < a.N) ? el[(size_t)u * a.ldk + k1] : elg[(size_t)(u - a.N) * a.ldk + k1];
+            const float s = lrelu02(el_u + er_v);
             const float mn = fmaxf(m, s);
             den = den * __expf(m - mn) + __expf(s - mn);
             m = mn;
@@ -48,9 +50,10 @@ __global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const flo
 
 constexpr int GATMH_BLK_ROWS = 64;   // destination rows per workgroup (as K1b)
 
-template <int GROUP>
+template <int GROUP, bool GH>
 __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
-                                                                    const float *el, const float *er,
+                                                                    const float *zg, const float *el,
+                                                                    const float *elg, const float *er,
                                                                     const float *m_in, const float *den_in,
                                                                     float *partial, uint32_t tiles, uint32_t rounds) {
     constexpr int RPW = 64 / GROUP;
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
     const uint32_t ccol = col_ok ? col : 0;
     const uint32_t k = min((ccol * 4) / a.D, a.K - 1);          // one head per float4 (D % 4 == 0, or a single head)
     const float4 *z4 = reinterpret_cast<const float4 *>(z);
+    const float4 *zg4 = reinterpret_cast<const float4 *>(zg);
     float4 *p4 = reinterpret_cast<float4 *>(partial) + (size_t)b * a.N * nchunk;
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = (uint32_t)__shfl((int)my_idx, j + u, GROUP);
-                    x[u] = z4[(size_t)s * nchunk + ccol];
-                    w[u] = el[(size_t)s * a.ldk + k];
+                    x[u] = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
+                    w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -109,8 +113,9 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
             }
             for (; j < n; ++j) {
                 const uint32_t s = (uint32_t)__shfl((int)my_idx, j, GROUP);
-                const float4 x = z4[(size_t)s * nchunk + ccol];
-                const float al = __expf(lrelu02(el[(size_t)s * a.ldk + k] + er_v) - m_v) * idn;
+                const float4 x = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
+                const float el_s = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
+                const float al = __expf(lrelu02(el_s + er_v) - m_v) * idn;
                 acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
                 acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
             }
@@ -149,24 +154,28 @@ __global__ __launch_bounds__(256) void gatmh_forward_reduce_kernel(GatMhArgs a, 
 
 hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
                                         const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
-                                        const float *z, const float *el, const float *er, float *o, float *m,
-                                        float *den, float *partial, hipStream_t s) {
+                                        const float *z, const float *zg, const float *el, const float *elg,
+                                        const float *er, float *o, float *m, float *den, float *partial, bool ghosts,
+                                        hipStream_t s) {
     if (N == 0) return hipSuccess;
     if (!gatmh_shape_ok(K, D) || ((D & 3) && K != 1) || (ld & 3) || B.nb == 0) return hipErrorInvalidValue;
     GatMhArgs a{N, K, D, ld, ldk, colptr, rowidx};
-    hipLaunchKernelGGL(gatmh_stats_kernel, dim3((N + 3) / 4), dim3(256), 0, s, a, el, er, m, den);
+    if (ghosts) hipLaunchKernelGGL(gatmh_stats_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
+    else hipLaunchKernelGGL(gatmh_stats_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
     const uint32_t nchunk = ld >> 2;
     const int group = ld >= 128 ? 32 : 16;
     const uint32_t slabs = (((K * D + 3) >> 2) + group - 1) / group;
     const uint32_t tiles = (N + GATMH_BLK_ROWS - 1) / GATMH_BLK_ROWS, rounds = (B.nb + 7) / 8;
     const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (group == 32)
-        hipLaunchKernelGGL(gatmh_forward_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, el, er, m,
-                           den, partial, tiles, rounds);
-    else
-        hipLaunchKernelGGL(gatmh_forward_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, el, er, m,
-                           den, partial, tiles, rounds);
+#define GATMH_FWD(G, H)                                                                                                  \
+    hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, el, elg, er, \
+                       m, den, partial, tiles, rounds)
+    if (group == 32 && ghosts) GATMH_FWD(32, true);
+    else if (group == 32) GATMH_FWD(32, false);
+    else if (ghosts) GATMH_FWD(16, true);
+    else GATMH_FWD(16, false);
+#undef GATMH_FWD
     const size_t n = (size_t)N * nchunk;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(gatmh_forward_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den,
@@ -184,9 +193,10 @@ __device__ __forceinline__ float head_lanes_sum(float v, int HL) {
     return v;
 }
 
-template <int GROUP>
+template <int GROUP, bool GH>
 __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
-                                                                    const float *el, const float *er,
+                                                                    const float *zg, const float *el,
+                                                                    const float *elg, const float *er,
                                                                     const float *m_in, const float *den_in,
                                                                     const float *d_o, float4 *pst /*[nb][N][K]*/,
                                                                     uint32_t tiles, uint32_t rounds, int HL) {
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
     const uint32_t ccol = col_ok ? col : 0;
     const uint32_t k = min((ccol * 4) / a.D, a.K - 1);
     const float4 *z4 = reinterpret_cast<const float4 *>(z);
+    const float4 *zg4 = reinterpret_cast<const float4 *>(zg);
     const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
@@ -236,8 +247,8 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
                 for (int u = 0; u < 4; ++u) {
                     const int jj = j + u < n ? j + u : n - 1;      // dead slots repeat the last edge, weight 0 below
                     const uint32_t s = (uint32_t)__shfl((int)my_idx, jj, GROUP);
-                    x[u] = z4[(size_t)s * nchunk + ccol];
-                    w[u] = el[(size_t)s * a.ldk + k];
+                    x[u] = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
+                    w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
 // t, der, st4 = (er, m, 1/den, t): blocks in order, then the self edge
 __global__ void gatmh_bwd_dst_reduce_kernel(GatMhArgs a, uint32_t nb, const float4 *pst, const float *z, const float *el,
                                             const float *er, const float *m_in, const float *den_in, const float *d_o,
-                                            float *t_out, float *der_out, float4 *st4) {
+                                            float *t_out, float *der_out, float4 *st4, uint32_t lds4) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)a.N * a.K) return;
     const uint32_t v = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
@@ -283,13 +294,14 @@ __global__ void gatmh_bwd_dst_reduce_kernel(GatMhArgs a, uint32_t nb, const floa
     a2 = fmaf(al, lp, a2);
     t_out[vk] = t;
     der_out[vk] = a1 - t * a2;
-    st4[(size_t)v * a.K + k] = make_float4(er[vk], m_in[vk], idn, t);
+    st4[(size_t)v * lds4 + k] = make_float4(er[vk], m_in[vk], idn, t);
 }
 
-template <int GROUP>
+template <int GROUP, bool GH>
 __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
                                                                     const float *el, const float4 *st4,
-                                                                    const float *d_o, float *pdz /*[nb][N][ld]*/,
+                                                                    const float4 *stg, uint32_t lds4, const float *d_o,
+                                                                    const float *dog, float *pdz /*[nb][N][ld]*/,
                                                                     float *pdel /*[nb][N][K]*/, uint32_t tiles,
                                                                     uint32_t rounds, int HL) {
     constexpr int RPW = 64 / GROUP;
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a,
     const uint32_t k = min((ccol * 4) / a.D, a.K - 1);
     const float4 *z4 = reinterpret_cast<const float4 *>(z);
     const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
+    const float4 *dog4 = reinterpret_cast<const float4 *>(dog);
     float4 *p4 = reinterpret_cast<float4 *>(pdz) + (size_t)b * a.N * nchunk;
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
@@ -337,9 +350,9 @@ __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a,
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int jj = j + c < n ? j + c : n - 1;
-                    const uint32_t v = (uint32_t)__shfl((int)my_idx, jj, GROUP);
-                    x[c] = do4[(size_t)v * nchunk + ccol];
-                    sv[c] = st4[(size_t)v * a.K + k];
+                    const uint32_t v = (uint32_t)__shfl((int)my_idx, jj, GROUP);   // ids >= N: ghost destinations
+                    x[c] = ((!GH || v < a.N) ? do4 + (size_t)v * nchunk : dog4 + (size_t)(v - a.N) * nchunk)[ccol];
+                    sv[c] = (!GH || v < a.N) ? st4[(size_t)v * lds4 + k] : stg[(size_t)(v - a.N) * lds4 + k];
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a,
 
 // del[u,k] = sum_b pdel + self edge
 __global__ void gatmh_bwd_del_reduce_kernel(GatMhArgs a, uint32_t nb, const float *pdel, const float *z, const float *el,
-                                            const float4 *st4, const float *d_o, float *del_out) {
+                                            const float4 *st4, uint32_t lds4, const float *d_o, float *del_out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)a.N * a.K) return;
     const uint32_t u = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
@@ -374,7 +387,7 @@ __global__ void gatmh_bwd_del_reduce_kernel(GatMhArgs a, uint32_t nb, const floa
     const float *zr = z + (size_t)u * a.ld + (size_t)k * a.D, *dr = d_o + (size_t)u * a.ld + (size_t)k * a.D;
     float da = 0.f;
     for (uint32_t d = 0; d < a.D; ++d) da = fmaf(dr[d], zr[d], da);
-    const float4 sv = st4[(size_t)u * a.K + k];
+    const float4 sv = st4[(size_t)u * lds4 + k];
     const float pre = el[(size_t)u * a.ldk + k] + sv.x;
     const float al = __expf(lrelu02(pre) - sv.y) * sv.z;
     const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
@@ -384,8 +397,9 @@ __global__ void gatmh_bwd_del_reduce_kernel(GatMhArgs a, uint32_t nb, const floa
 
 // dz[u,:] = sum_b pdz[b][u,:] + alpha_self dO[u,:] + del[u,k] a_l + der[u,k] a_r
 __global__ __launch_bounds__(256) void gatmh_bwd_dz_reduce_kernel(GatMhArgs a, uint32_t nb, const float *pdz,
-                                                                  const float *el, const float4 *st4, const float *d_o,
-                                                                  const float *del, const float *der, const float *a_l,
+                                                                  const float *el, const float4 *st4, uint32_t lds4,
+                                                                  const float *d_o, const float *del, const float *der,
+                                                                  const float *a_l,
                                                                   const float *a_r, float *dz) {
     const uint32_t nchunk = a.ld >> 2;
     const size_t n = (size_t)a.N * nchunk;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dz_reduce_kernel(GatMhArgs a, u
             const float4 p = p4[(size_t)b * n + i];
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
-        const float4 sv = st4[(size_t)u * a.K + k];
+        const float4 sv = st4[(size_t)u * lds4 + k];
         const float al = __expf(lrelu02(el[(size_t)u * a.ldk + k] + sv.x) - sv.y) * sv.z;   // self edge
         const float4 x = do4[i];
         const float dl = del[(size_t)u * a.ldk + k], dr = der[(size_t)u * a.ldk + k];
@@ -422,51 +436,78 @@ static int gatmh_blocked_hl(uint32_t K, uint32_t D, uint32_t ld) {
     return (int)(D / 4);
 }
 
-hipError_t launch_gatmh_backward_blocked(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
-                                         const BlockedAdj &Bin, const BlockedAdj &Bout, const float *z, const float *el,
-                                         const float *er, const float *m, const float *den, const float *d_o,
-                                         const float *a_l, const float *a_r, float *t, float *del, float *der, float *dz,
-                                         float *partial /*nb x N x (ld + K) floats*/, float4 *st4, hipStream_t s) {
-    if (N == 0) return hipSuccess;
-    const int HL = gatmh_blocked_hl(K, D, ld);
-    if (!HL || !gatmh_shape_ok(K, D) || Bin.nb == 0 || Bout.nb == 0 || 4 * K > ld) return hipErrorInvalidValue;
-    GatMhArgs a{N, K, D, ld, ldk, nullptr, nullptr};
-    const int group = ld >= 128 ? 32 : 16;
-    const uint32_t slabs = (((K * D + 3) >> 2) + group - 1) / group;
-    const uint32_t tiles = (N + GATMH_BLK_ROWS - 1) / GATMH_BLK_ROWS;
-    const int nk_blocks = (int)(((uint64_t)N * K + 255) / 256);
+// The backward sweep in its two phases.  Between them a partitioned run exchanges the ghost rows of dO and st4
+// (destinations of local out-edges owned elsewhere); a single partition just calls both.
+struct GatMhBwdPlan {
+    int HL, group;
+    uint32_t slabs, tiles;
+    int nk_blocks, row_blocks;
+};
+static bool gatmh_bwd_plan(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, GatMhBwdPlan *p) {
+    p->HL = gatmh_blocked_hl(K, D, ld);
+    if (!p->HL || !gatmh_shape_ok(K, D) || 4 * K > ld) return false;
+    p->group = ld >= 128 ? 32 : 16;
+    p->slabs = (((K * D + 3) >> 2) + p->group - 1) / p->group;
+    p->tiles = (N + GATMH_BLK_ROWS - 1) / GATMH_BLK_ROWS;
+    p->nk_blocks = (int)(((uint64_t)N * K + 255) / 256);
     const size_t nrow4 = (size_t)N * (ld >> 2);
-    const int row_blocks = (int)((nrow4 + 255) / 256 < 8192 ? (nrow4 + 255) / 256 : 8192);
-    {   // destination side over the in-edges
-        const uint32_t rounds = (Bin.nb + 7) / 8;
-        const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
-        if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        float4 *pst = reinterpret_cast<float4 *>(partial);
-        if (group == 32)
-            hipLaunchKernelGGL(gatmh_bwd_dst_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, el, er, m,
-                               den, d_o, pst, tiles, rounds, HL);
-        else
-            hipLaunchKernelGGL(gatmh_bwd_dst_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, el, er, m,
-                               den, d_o, pst, tiles, rounds, HL);
-        hipLaunchKernelGGL(gatmh_bwd_dst_reduce_kernel, dim3(nk_blocks), dim3(256), 0, s, a, Bin.nb, pst, z, el, er, m, den,
-                           d_o, t, der, st4);
-    }
-    {   // source side over the out-edges
-        const uint32_t rounds = (Bout.nb + 7) / 8;
-        const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
-        if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        float *pdz = partial, *pdel = partial + (size_t)Bout.nb * N * ld;
-        if (group == 32)
-            hipLaunchKernelGGL(gatmh_bwd_src_blocked_kernel<32>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bout, z, el, st4,
-                               d_o, pdz, pdel, tiles, rounds, HL);
-        else
-            hipLaunchKernelGGL(gatmh_bwd_src_blocked_kernel<16>, dim3((uint32_t)grid), dim3(256), 0, s, a, Bout, z, el, st4,
-                               d_o, pdz, pdel, tiles, rounds, HL);
-        hipLaunchKernelGGL(gatmh_bwd_del_reduce_kernel, dim3(nk_blocks), dim3(256), 0, s, a, Bout.nb, pdel, z, el, st4, d_o,
-                           del);
-        hipLaunchKernelGGL(gatmh_bwd_dz_reduce_kernel, dim3(row_blocks), dim3(256), 0, s, a, Bout.nb, pdz, el, st4, d_o,
-                           del, der, a_l, a_r, dz);
-    }
+    p->row_blocks = (int)((nrow4 + 255) / 256 < 8192 ? (nrow4 + 255) / 256 : 8192);
+    return true;
+}
+
+// phase A, destination side over the in-edges: t, der and st4 = (er, m, 1/den, t) of every local (v, k)
+hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                             const BlockedAdj &Bin, const float *z, const float *zg, const float *el,
+                                             const float *elg, const float *er, const float *m, const float *den,
+                                             const float *d_o, float *t, float *der, float *partial, float4 *st4,
+                                             uint32_t lds4, bool ghosts, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    GatMhBwdPlan p;
+    if (!gatmh_bwd_plan(N, K, D, ld, &p) || Bin.nb == 0) return hipErrorInvalidValue;
+    GatMhArgs a{N, K, D, ld, ldk, nullptr, nullptr};
+    const uint32_t rounds = (Bin.nb + 7) / 8;
+    const uint64_t grid = (uint64_t)p.slabs * rounds * p.tiles * 8;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    float4 *pst = reinterpret_cast<float4 *>(partial);
+#define GATMH_DST(G, H)                                                                                                  \
+    hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<G, H>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,  \
+                       er, m, den, d_o, pst, p.tiles, rounds, p.HL)
+    if (p.group == 32 && ghosts) GATMH_DST(32, true);
+    else if (p.group == 32) GATMH_DST(32, false);
+    else if (ghosts) GATMH_DST(16, true);
+    else GATMH_DST(16, false);
+#undef GATMH_DST
+    hipLaunchKernelGGL(gatmh_bwd_dst_reduce_kernel, dim3(p.nk_blocks), dim3(256), 0, s, a, Bin.nb, pst, z, el, er, m, den, d_o,
+                       t, der, st4, lds4);
+    return hipGetLastError();
+}
+
+// phase B, source side over the out-edges: del and dz (needs dO and st4 of the ghost destinations too)
+hipError_t launch_gatmh_backward_blocked_src(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
+                                             const BlockedAdj &Bout, const float *z, const float *el, const float *d_o,
+                                             const float *dog, const float4 *st4, const float4 *stg, uint32_t lds4,
+                                             const float *der, const float *a_l, const float *a_r, float *del, float *dz,
+                                             float *partial, bool ghosts, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    GatMhBwdPlan p;
+    if (!gatmh_bwd_plan(N, K, D, ld, &p) || Bout.nb == 0) return hipErrorInvalidValue;
+    GatMhArgs a{N, K, D, ld, ldk, nullptr, nullptr};
+    const uint32_t rounds = (Bout.nb + 7) / 8;
+    const uint64_t grid = (uint64_t)p.slabs * rounds * p.tiles * 8;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    float *pdz = partial, *pdel = partial + (size_t)Bout.nb * N * ld;
+#define GATMH_SRC(G, H)                                                                                                  \
+    hipLaunchKernelGGL((gatmh_bwd_src_blocked_kernel<G, H>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bout, z, el, st4, stg,  \
+                       lds4, d_o, dog, pdz, pdel, p.tiles, rounds, p.HL)
+    if (p.group == 32 && ghosts) GATMH_SRC(32, true);
+    else if (p.group == 32) GATMH_SRC(32, false);
+    else if (ghosts) GATMH_SRC(16, true);
+    else GATMH_SRC(16, false);
+#undef GATMH_SRC
+    hipLaunchKernelGGL(gatmh_bwd_del_reduce_kernel, dim3(p.nk_blocks), dim3(256), 0, s, a, Bout.nb, pdel, z, el, st4, lds4, d_o,
+                       del);
+    hipLaunchKernelGGL(gatmh_bwd_dz_reduce_kernel, dim3(p.row_blocks), dim3(256), 0, s, a, Bout.nb, pdz, el, st4, lds4, d_o, del,
+                       der, a_l, a_r, dz);
     return hipGetLastError();
 }
 

@@ -74,7 +74,12 @@ int dory_configure(dory_ctx *ctx, int gnn_type, uint32_t num_layers,
  * Tensors: h z el er m den o do dz t del der (+ logits grad lab at L-1), weights w a_l a_r.
  * Stage mapping: apply_vertex fwd = z=h*W; apply_edge fwd = el,er; aggregate fwd = edge softmax
  * + weighted sum (+ELU / head mean); predict_gat = softmax - label; aggregate bwd = attention
- * backward (dz, da_l, da_r); apply_vertex bwd = dW, dh.  Single partition only in this version. */
+ * backward (dz, da_l, da_r); apply_vertex bwd = dW, dh.  Partitioned runs: dory_halo_exchange(layer, FORWARD) ships
+ * "z" -> "fg_z" (the ghost sources' scores are recomputed from it); the backward sweep of dory_aggregate runs in two
+ * phases and ships "do" -> "bg_do" and "st" -> "bg_st" (the packed (er, m, 1/den, t) rows) of the out-edges' ghost
+ * destinations in between -- itself over RCCL, or, with option "gatmh_bwd_phase" = 1 / 2, one phase per call so that
+ * the caller can move those rows (dory_halo_pack_tensor / dory_halo_unpack_tensor); dory_halo_exchange(layer,
+ * BACKWARD) is a no-op for this model.  Partitioned runs need the source-blocked kernels ("gatmh_blocked" = 1). */
 int dory_gatmh_heads(dory_ctx *ctx, const uint32_t *heads);
 
 /* Upload one partition's adjacency, exactly the arrays of Graph
@@ -166,6 +171,11 @@ int dory_halo_exchange(dory_ctx *ctx, uint32_t layer, int dir);
  * buffers are device pointers of total_send_rows x cols / total_recv_rows x cols */
 int dory_halo_pack(dory_ctx *ctx, uint32_t layer, int dir, float *send_buf);
 int dory_halo_unpack(dory_ctx *ctx, uint32_t layer, int dir, const float *recv_buf);
+/* The same for any named tensor: rows of a per-local-vertex tensor listed in the plan of `dir` -> send_buf, and
+ * recv_buf -> the rows of a ghost tensor of that direction (foreign transports; what the multi-head GAT extension's
+ * backward sweep ships between its two phases: "do" -> "bg_do", "st" -> "bg_st"). */
+int dory_halo_pack_tensor(dory_ctx *ctx, uint32_t layer, const char *name, int dir, float *send_buf);
+int dory_halo_unpack_tensor(dory_ctx *ctx, uint32_t layer, const char *name, int dir, const float *recv_buf);
 
 /* ---- weight-gradient reduction + optimiser (replaces the weight server's
  * PUB/SUB all-gather-and-sum + Adam, src/weight-server/weightserver.cpp:89-187,

@@ -87,3 +87,111 @@ def test_gat_mh_rejects_bad_shapes():
     with pytest.raises(da.DoryError):
         ctx.preallocate()
     ctx.close()
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_gat_mh_partitioned_epoch_vs_oracle(P):
+    """P partitions (one context each, ghost rows moved by pack / unpack + a device copy, i.e. everything of the
+    multi-GPU path but RCCL itself): forward exchange of z, scores of the ghost sources recomputed locally, the
+    backward sweep in its two phases with dO and st shipped in between -- against the single-partition float64 oracle."""
+    import torch
+    import dorylus_amd as da
+    import gat_mh_oracle as go
+    import partition_oracle as po
+    from dorylus_amd.halo import halo_plan
+    from helpers import rel_err
+    dims, heads, V, E = [24, 64, 6], [4, 1], 240, 2600
+    rng = np.random.default_rng(17)
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    parts = (rng.permutation(V) % P).astype(np.int64)                 # scattered ownership: many ghosts
+    g_all = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    gs = [po.preprocess(s, d, parts, r, P) for r in range(P)]
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    params = []
+    for l in range(2):
+        zw = dims[l + 1] * (heads[l] if l == 1 else 1)
+        params.append([(rng.standard_normal((dims[l], zw)) / np.sqrt(dims[l])).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32)])
+    ctxs, plans = [], []
+    for r, g in enumerate(gs):
+        ctx = da.Context(0)
+        ctx.configure(da.GATMH, dims, V, r, P)
+        ctx.gatmh_heads(heads)
+        ctx.set_option("spmm_blk_nb", 8)
+        ctx.graph_upload(g)
+        ctx.preallocate()
+        ctx.upload(0, "h", X[g["localToGlobal"]])
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l, (W, al, ar) in enumerate(params):
+            ctx.weight_set(l, "w", W); ctx.weight_set(l, "a_l", al); ctx.weight_set(l, "a_r", ar)
+        pl = halo_plan(g, parts, r, P)
+        for dd in (0, 1):
+            ctx.halo_plan(dd, pl[dd][0], pl[dd][1])
+        ctxs.append(ctx)
+        plans.append(pl)
+
+    def exchange(layer, src_name, ghost_name, dd):
+        _, _, ld, _ = ctxs[0].info(layer, src_name)
+        send = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][0])) * ld, device="cuda") for r in range(P)]
+        recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][1])) * ld, device="cuda") for r in range(P)]
+        for r in range(P):
+            ctxs[r].halo_pack_tensor(layer, src_name, dd, send[r].data_ptr())
+            ctxs[r].sync()
+        for r in range(P):
+            soff = np.concatenate([[0], np.cumsum([len(x) for x in plans[r][dd][0]])])
+            for p in range(P):
+                roff = np.concatenate([[0], np.cumsum([len(x) for x in plans[p][dd][1]])])
+                n = len(plans[r][dd][0][p])
+                recv[p][roff[r] * ld:(roff[r] + n) * ld] = send[r][soff[p] * ld:(soff[p] + n) * ld]
+        torch.cuda.synchronize()
+        for r in range(P):
+            ctxs[r].halo_unpack_tensor(layer, ghost_name, dd, recv[r].data_ptr())
+            ctxs[r].sync()
+
+    L = 2
+    for l in range(L):
+        for c in ctxs:
+            c.apply_vertex(l, da.FORWARD)
+        exchange(l, "z", "fg_z", da.FORWARD)
+        for c in ctxs:
+            c.apply_edge(l + 1, da.FORWARD)
+            c.aggregate(l + 1, da.FORWARD)
+    for c in ctxs:
+        c.predict_gat(L)
+    for l in range(L - 1, -1, -1):
+        for c in ctxs:
+            c.set_option("gatmh_bwd_phase", 1)
+            c.aggregate(l + 1, da.BACKWARD)
+        exchange(l, "do", "bg_do", da.BACKWARD)
+        exchange(l, "st", "bg_st", da.BACKWARD)
+        for c in ctxs:
+            c.set_option("gatmh_bwd_phase", 2)
+            c.aggregate(l + 1, da.BACKWARD)
+            c.apply_vertex(l, da.BACKWARD)
+
+    fws, Hs, loss, dlogits, grads = go.epoch(g_all, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
+
+    def gathered(layer, name):
+        out = None
+        for r, g in enumerate(gs):
+            t = ctxs[r].download(layer, name)
+            if out is None:
+                out = np.zeros((V, t.shape[1]), np.float32)
+            out[g["localToGlobal"]] = t
+        return out
+
+    for l in range(L):
+        assert rel_err(gathered(l, "z"), fws[l]["Z"]) < RTOL, (l, "z")
+        assert rel_err(gathered(l, "o"), fws[l]["O"]) < RTOL, (l, "o")
+        assert rel_err(gathered(l, "t"), grads[l]["t"]) < 5e-4, (l, "t")
+        assert rel_err(gathered(l, "del"), grads[l]["d_el"]) < 5e-4, (l, "del")
+        assert rel_err(gathered(l, "der"), grads[l]["d_er"]) < 5e-4, (l, "der")
+        assert rel_err(gathered(l, "dz"), grads[l]["dZ"]) < 5e-4, (l, "dz")
+        assert rel_err(sum(c.weight_grad_get(l, "w") for c in ctxs), grads[l]["dW"]) < 5e-4, (l, "dW")
+        assert rel_err(sum(c.weight_grad_get(l, "a_l") for c in ctxs).ravel(), grads[l]["da_l"]) < 5e-4, (l, "da_l")
+        assert rel_err(sum(c.weight_grad_get(l, "a_r") for c in ctxs).ravel(), grads[l]["da_r"]) < 5e-4, (l, "da_r")
+    assert rel_err(gathered(1, "logits"), Hs[2]) < RTOL
+    for c in ctxs:
+        c.close()
