@@ -62,7 +62,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.val = val;
     a.self_scale = c->norm;
     a.self_mode = self_mode;
-    a.xl = xl.d; a.xg = xg ? xg->d : nullptr; a.out = out.d;
+    a.xl = xl.d; a.xg = (xg && xg->rows) ? xg->d : nullptr; a.out = out.d;   // nullptr: no ghost rows (the blocked kernel then skips the select)
     a.accumulate = accumulate;
     a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
     const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal

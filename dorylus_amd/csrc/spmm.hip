@@ -417,7 +417,7 @@ void free_blocked(BlockedAdj *B) {
     *B = BlockedAdj{};
 }
 
-template <int GROUP, bool UNIT>
+template <int GROUP, bool UNIT, bool GH>   // GH: ids >= N are ghost rows; a partition without ghosts compiles the select out
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAdj B, float *partial,
                                                            uint32_t tiles, uint32_t round0, uint32_t rounds,
                                                            uint32_t b_lo, uint32_t b_hi) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = bcast_u32<GROUP>(my_idx, j + u);
                     w[u] = UNIT ? 1.f : bcast_f32<GROUP>(my_val, j + u);
-                    const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
+                    const float4 *row = (!GH || s < a.N) ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
                     x[u] = row[ccol];
                 }
 #pragma unroll
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
             for (; j < n; ++j) {
                 const uint32_t s = bcast_u32<GROUP>(my_idx, j);
                 const float w = UNIT ? 1.f : bcast_f32<GROUP>(my_val, j);
-                const float4 *row = s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
+                const float4 *row = (!GH || s < a.N) ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk;
                 acc = fma4(w, row[ccol], acc);
             }
             e += n;
@@ -555,19 +555,26 @@ hipError_t launch_spmm_blocked_part(const SpmmArgs &a, const BlockedAdj &B, floa
     const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 gr((uint32_t)grid), bl(256);
-#define LAUNCH_BLK(G)                                                                                         \
+    const bool gh = a.xg != nullptr;   // callers pass nullptr when the partition has no ghost rows
+#define LAUNCH_BLK_U(G, U)                                                                                    \
     do {                                                                                                      \
-        if (unit)                                                                                             \
-            hipLaunchKernelGGL((spmm_blocked_kernel<G, true>), gr, bl, 0, s, a, B, partial, tiles, round0,     \
+        if (gh)                                                                                               \
+            hipLaunchKernelGGL((spmm_blocked_kernel<G, U, true>), gr, bl, 0, s, a, B, partial, tiles, round0,  \
                                rounds, b_lo, b_hi);                                                           \
         else                                                                                                  \
-            hipLaunchKernelGGL((spmm_blocked_kernel<G, false>), gr, bl, 0, s, a, B, partial, tiles, round0,    \
+            hipLaunchKernelGGL((spmm_blocked_kernel<G, U, false>), gr, bl, 0, s, a, B, partial, tiles, round0, \
                                rounds, b_lo, b_hi);                                                           \
+    } while (0)
+#define LAUNCH_BLK(G)                                                                                         \
+    do {                                                                                                      \
+        if (unit) LAUNCH_BLK_U(G, true);                                                                      \
+        else LAUNCH_BLK_U(G, false);                                                                          \
     } while (0)
     if (group == 8) LAUNCH_BLK(8);
     else if (group == 16) LAUNCH_BLK(16);
     else LAUNCH_BLK(32);
 #undef LAUNCH_BLK
+#undef LAUNCH_BLK_U
     return hipGetLastError();
 }
 
