@@ -50,6 +50,20 @@ def synth_edges(kind, V, E, seed=42):
         perm = rng.permutation(V).astype(np.uint32)
         s = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
         d = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
+    elif kind == "rmat":
+        # R-MAT, a=.57 b=.19 c=.19 d=.05, 18 levels (2^18 >= V; ids folded back with mod V), ids shuffled.
+        # Far more skewed than real Reddit: the top vertices carry ~1 % of all endpoints each.
+        levels = 18
+        s = np.zeros(half, np.uint32)
+        d = np.zeros(half, np.uint32)
+        for _ in range(levels):
+            r = rng.random(half, dtype=np.float32)
+            sb = (r >= 0.76).astype(np.uint32)                       # quadrants c, d: source bit 1
+            db = (((r >= 0.57) & (r < 0.76)) | (r >= 0.95)).astype(np.uint32)   # quadrants b, d: destination bit 1
+            s = (s << np.uint32(1)) | sb
+            d = (d << np.uint32(1)) | db
+        perm = rng.permutation(V).astype(np.uint32)
+        s, d = perm[s % np.uint32(V)], perm[d % np.uint32(V)]
     elif kind == "hub":
         # uniform, plus one vertex that is an endpoint of 1 % of all edges (degree ~1.1 M: 50x real Reddit's maximum):
         # the stress case for anything that walks a row's edge list on one lane group
@@ -121,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "community", "hub"])
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "rmat", "community", "hub"])
     ap.add_argument("--scale", type=float, default=1.0, help="edge-count scale (1.0 = Reddit)")
     ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS),
                     help="graph/model shape; anything but reddit is a scale test, not the BASELINE metric line")
