@@ -95,6 +95,10 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 if ((rc = wait_halo(c))) return rc;
                 HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, B.nb, c->compute));
             }
+            if (B.nchunks) {   // hubs: the remainder of the (block,row) segments K1b stopped in
+                if ((rc = ensure_scratch(c, (size_t)B.nchunks * a.ld * sizeof(float)))) return rc;
+                HIPCK(c, launch_spmm_blocked_long_segments(a, B, c->partial, row_scale != nullptr, c->scratch, c->compute));
+            }
             HIPCK(c, launch_spmm_blocked_reduce(a, B, c->partial, row_scale, c->compute));
             return DORY_OK;
         }

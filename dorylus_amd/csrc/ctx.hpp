@@ -50,7 +50,16 @@ struct BlockedAdj {
     uint32_t *boff = nullptr;   // [nb][N+1]: row offsets inside the block
     uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order
     float *bval = nullptr;      // nnz
+    // (block,row) segments longer than BLK_SEG_CLAMP edges (hubs): K1b stops there, the remainder is cut into chunks
+    // of BLK_SEG_CHUNK edges for workgroup-per-chunk kernels (spmm.hip); all empty on graphs without such segments
+    uint32_t seg_clamp = 0;             // 0: no long segments
+    uint32_t nsegs = 0, nchunks = 0;
+    uint32_t *seg_row = nullptr;        // nsegs: destination row
+    uint32_t *seg_blk = nullptr;        // nsegs: source block
+    uint32_t *seg_chunk_ptr = nullptr;  // nsegs+1
+    uint32_t *seg_chunks = nullptr;     // 6 words per chunk: row, block, e0 (lo, hi), e1 (lo, hi): absolute positions in bidx
 };
+constexpr uint32_t BLK_SEG_CLAMP = 2048, BLK_SEG_CHUNK = 4096;
 // K1's long rows (hubs): the part of a row beyond LONG_ROW_CLAMP edges, in chunks of LONG_ROW_CHUNK edges
 constexpr uint32_t LONG_ROW_CLAMP = 8192, LONG_ROW_CHUNK = 4096;
 struct LongRowsHost {                    // plan_long_rows output
@@ -178,6 +187,9 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
 uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes);
 hipError_t launch_spmm_blocked_part(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, bool unit,
                                     uint32_t b_lo, uint32_t b_hi, hipStream_t s);
+// the long (block,row) segments' remainder added into their partial rows (between the part launches and the reduce)
+hipError_t launch_spmm_blocked_long_segments(const SpmmArgs &a, const BlockedAdj &B, float *partial, bool unit,
+                                             float *chunk_partial /*nchunks x ld*/, hipStream_t s);
 hipError_t launch_spmm_blocked_reduce(const SpmmArgs &a, const BlockedAdj &B, const float *partial,
                                       const float *row_scale, hipStream_t s);
 void free_blocked(BlockedAdj *B);

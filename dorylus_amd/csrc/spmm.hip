@@ -404,6 +404,40 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
     BCK(hipStreamSynchronize(s));
     (void)hipFree(cnt);
     (void)hipFree(dtotal);
+    {   // hubs: (block,row) segments beyond BLK_SEG_CLAMP edges are finished by workgroup-per-chunk kernels
+        std::vector<uint32_t> hoff((size_t)nb * (N + 1));
+        BCK(hipMemcpy(hoff.data(), B.boff, hoff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> srow, sblk, sptr(1, 0), chunks;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t *o = hoff.data() + (size_t)b * (N + 1);
+            for (uint32_t v = 0; v < N; ++v) {
+                const uint32_t len = o[v + 1] - o[v];
+                if (len <= BLK_SEG_CLAMP) continue;
+                srow.push_back(v);
+                sblk.push_back(b);
+                const uint64_t beg = base[b] + o[v] + BLK_SEG_CLAMP, end = base[b] + o[v + 1];
+                for (uint64_t e = beg; e < end; e += BLK_SEG_CHUNK) {
+                    const uint64_t e1 = e + BLK_SEG_CHUNK < end ? e + BLK_SEG_CHUNK : end;
+                    chunks.insert(chunks.end(), {v, b, (uint32_t)(e & 0xFFFFFFFFu), (uint32_t)(e >> 32),
+                                                 (uint32_t)(e1 & 0xFFFFFFFFu), (uint32_t)(e1 >> 32)});
+                }
+                sptr.push_back((uint32_t)(chunks.size() / 6));
+            }
+        }
+        if (!srow.empty()) {
+            B.seg_clamp = BLK_SEG_CLAMP;
+            B.nsegs = (uint32_t)srow.size();
+            B.nchunks = (uint32_t)(chunks.size() / 6);
+            auto up = [&](uint32_t **dst, const std::vector<uint32_t> &h) {
+                hipError_t e2 = hipMalloc((void **)dst, h.size() * sizeof(uint32_t));
+                return e2 != hipSuccess ? e2 : hipMemcpy(*dst, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            };
+            BCK(up(&B.seg_row, srow));
+            BCK(up(&B.seg_blk, sblk));
+            BCK(up(&B.seg_chunk_ptr, sptr));
+            BCK(up(&B.seg_chunks, chunks));
+        }
+    }
 #undef BCK
     *out = B;
     return hipSuccess;
@@ -414,6 +448,8 @@ void free_blocked(BlockedAdj *B) {
     if (B->bbase) (void)hipFree(B->bbase);
     if (B->bidx) (void)hipFree(B->bidx);
     if (B->bval) (void)hipFree(B->bval);
+    for (uint32_t *q : {B->seg_row, B->seg_blk, B->seg_chunk_ptr, B->seg_chunks})
+        if (q) (void)hipFree(q);
     *B = BlockedAdj{};
 }
 
@@ -456,7 +492,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
         const uint32_t v = tile * BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
         const bool row_ok = v < a.N;
         uint64_t e = row_ok ? base + boff[v] : 0;
-        const uint64_t end = row_ok ? base + boff[v + 1] : 0;
+        uint64_t end = row_ok ? base + boff[v + 1] : 0;
+        if (B.seg_clamp && end - e > B.seg_clamp) end = e + B.seg_clamp;   // hub segment: spmm_longseg_kernel does the rest
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         while (e < end) {
             const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
@@ -493,6 +530,83 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(SpmmArgs a, BlockedAd
             __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(p4 + (size_t)v * nchunk + col));
         }
     }
+}
+
+// remainder of a long (block,row) segment: one workgroup per chunk of BLK_SEG_CHUNK edges of the blocked copy, the
+// whole row width per wave, wave partials added in wave order (the K1 long-row kernel on the blocked arrays)
+template <bool UNIT>
+__global__ __launch_bounds__(256) void spmm_longseg_kernel(SpmmArgs a, BlockedAdj B, float *chunk_partial) {
+    extern __shared__ float4 seg_lds4[];                 // [4][nchunk]
+    const uint32_t *ch = B.seg_chunks + (size_t)blockIdx.x * 6;
+    const uint64_t e0 = ch[2] | ((uint64_t)ch[3] << 32), e1 = ch[4] | ((uint64_t)ch[5] << 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nchunk = a.ld >> 2;
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
+    const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg);
+    const uint64_t q = (e1 - e0 + 3) / 4;
+    const uint64_t wb = e0 + (uint64_t)wave * q, we = wb + q < e1 ? wb + q : e1;
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += 64) {
+        const uint32_t col = c0 + lane;
+        const bool act = col < nchunk;
+        const uint32_t cc = act ? col : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint64_t e = wb;
+        for (; e + 4 <= we; e += 4) {
+            float4 x[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t s = B.bidx[e + u];         // wave-uniform
+                w[u] = UNIT ? 1.f : B.bval[e + u];
+                x[u] = (s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk)[cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fma4(w[u], x[u], acc);
+        }
+        for (; e < we; ++e) {
+            const uint32_t s = B.bidx[e];
+            acc = fma4(UNIT ? 1.f : B.bval[e], (s < a.N ? xl4 + (size_t)s * nchunk : xg4 + (size_t)(s - a.N) * nchunk)[cc], acc);
+        }
+        if (act) seg_lds4[(size_t)wave * nchunk + col] = acc;
+    }
+    __syncthreads();
+    float4 *p4 = reinterpret_cast<float4 *>(chunk_partial) + (size_t)blockIdx.x * nchunk;
+    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+        float4 r = seg_lds4[col];
+        for (int w = 1; w < 4; ++w) {
+            const float4 t = seg_lds4[(size_t)w * nchunk + col];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        p4[col] = r;
+    }
+}
+
+// partial[block][row,:] += the segment's chunk sums, in chunk order (one workgroup per long segment)
+__global__ __launch_bounds__(256) void spmm_longseg_reduce_kernel(SpmmArgs a, BlockedAdj B, float *partial,
+                                                                  const float *chunk_partial) {
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t v = B.seg_row[blockIdx.x], b = B.seg_blk[blockIdx.x];
+    const uint32_t c_beg = B.seg_chunk_ptr[blockIdx.x], c_end = B.seg_chunk_ptr[blockIdx.x + 1];
+    const float4 *cp4 = reinterpret_cast<const float4 *>(chunk_partial);
+    float4 *row4 = reinterpret_cast<float4 *>(partial) + ((size_t)b * a.N + v) * nchunk;
+    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+        float4 acc = row4[col];
+        for (uint32_t c = c_beg; c < c_end; ++c) {
+            const float4 t = cp4[(size_t)c * nchunk + col];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        row4[col] = acc;
+    }
+}
+
+hipError_t launch_spmm_blocked_long_segments(const SpmmArgs &a, const BlockedAdj &B, float *partial, bool unit,
+                                             float *chunk_partial, hipStream_t s) {
+    if (!B.nchunks || a.ld == 0) return hipSuccess;
+    const size_t lds = (size_t)4 * (a.ld >> 2) * sizeof(float4);
+    if (unit) hipLaunchKernelGGL(spmm_longseg_kernel<true>, dim3(B.nchunks), dim3(256), lds, s, a, B, chunk_partial);
+    else hipLaunchKernelGGL(spmm_longseg_kernel<false>, dim3(B.nchunks), dim3(256), lds, s, a, B, chunk_partial);
+    hipLaunchKernelGGL(spmm_longseg_reduce_kernel, dim3(B.nsegs), dim3(256), 0, s, a, B, partial, chunk_partial);
+    return hipGetLastError();
 }
 
 // out[v,:] = self[v]*xl[v,:] + sum_b partial[b][v,:]   (block order; float4 streams)
