@@ -303,7 +303,7 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
 // 8 rows in flight) was within 2 % of this one (profiles/r01_k1b_forms_stream_vs_rowgroup.txt).
 // =======================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector for nontemporal ld/st
-constexpr int BLK_ROWS = 64;             // destination rows per workgroup
+constexpr int BLK_ROWS = 32;             // destination rows per workgroup (64: +2.5 % time, 16: same, 128: +6 %)
 
 __global__ __launch_bounds__(256) void blk_count_kernel(uint32_t N, const uint64_t *ptr, const uint32_t *idx,
                                                         uint32_t SB, uint32_t *cnt /*[nb][N]*/) {
