@@ -651,3 +651,29 @@ def test_errors_do_not_abort(da):
     with pytest.raises(da.DoryError):
         ctx.download(0, "nope")
     ctx.close()
+
+
+def test_rccl_communicator_inside_the_library(da):
+    """The RCCL calls the library makes itself (the N > 1 path cannot run on a one-GPU box: RCCL refuses two ranks on
+    one device): unique id, a one-rank communicator created next to torch's own RCCL, and an epoch after it."""
+    import partition_oracle as po
+    from helpers import make_ctx
+    rng = np.random.default_rng(5)
+    V = 200
+    s, d = rng.integers(0, V, 1500), rng.integers(0, V, 1500)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    ctx = make_ctx(da, g, [12, 8, 3], V)
+    uid = ctx.comm_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    ctx.comm_init(uid, 0, 1)
+    with pytest.raises(da.DoryError):
+        ctx.comm_init(uid, 1, 1)                      # rank out of range: refused before RCCL sees it
+    ctx.fill_uniform(0, "x", 1)
+    ctx.labels_upload((np.arange(V) % 3).astype(np.uint32))
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(2)
+    assert np.isfinite(ctx.weight_get(0, "w")).all()
+    eng.close()
+    ctx.close()
