@@ -165,7 +165,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()          # creates torch's communicator now, not inside the timed region
     import dorylus_amd as da
 
     global DIMS
@@ -208,8 +210,9 @@ def main():
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.from_numpy(ctx.comm_unique_id()))
-        dist.broadcast(idt, 0)
-        ctx.comm_init(idt.cpu().numpy(), rank, world)
+        with stdout_to_stderr():
+            dist.broadcast(idt, 0)
+            ctx.comm_init(idt.cpu().numpy(), rank, world)
     halo_ok = None
     if world > 1 and not gat:
         flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device="cuda")
@@ -346,6 +349,22 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+class stdout_to_stderr:
+    """RCCL prints a line ("Librccl path : ...") on stdout when a communicator is created; the driver reads the JSON
+    line from stdout, so file descriptor 1 points at stderr while communicators are being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def usable_cpus():

@@ -45,3 +45,14 @@ def test_bench_json_line_contract():
     assert cb["gpu_vs_oracle_rel_err_ah0"] < 1e-4
     tf = d["transform_first"]
     assert tf is None or tf["ms_per_step"] > 0
+
+
+def test_stdout_is_shielded_while_communicators_are_created():
+    """RCCL writes a line to file descriptor 1 when a communicator is created; bench.py points fd 1 at stderr for that time"""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.stdout_to_stderr():\n"
+            "    os.write(1, b'noise from a library\\n')\n"
+            "print('{\"json\": 1}')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == '{"json": 1}' and "noise from a library" in r.stderr
