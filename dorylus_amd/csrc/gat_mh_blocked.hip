@@ -188,8 +188,16 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
 // a head (a single head spans the whole group), so <dO[v,k,:], Z[u,k,:]> is a 4-term dot per lane plus log2(HL)
 // xor-shuffles inside the head.  Destination side: per-(block, v, k) partial (t, a1, a2); source side: per-block
 // partial dZ rows and partial del; small reduce kernels add the blocks in order, then the self edge.
+// sum over the HL neighbouring lanes of a head.  The first two butterfly steps stay inside a quad: DPP quad_perm
+// ([1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E) moves the operand in the VALU instead of a ds_bpermute round trip through LDS
+__device__ __forceinline__ float dpp_quad(float v, int ctrl_b1_or_4e) {
+    return ctrl_b1_or_4e == 0xB1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true))
+                                 : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float head_lanes_sum(float v, int HL) {
-    for (int o = 1; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (HL >= 2) v += dpp_quad(v, 0xB1);
+    if (HL >= 4) v += dpp_quad(v, 0x4E);
+    for (int o = 4; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
