@@ -171,13 +171,16 @@ int dory_create(int device, dory_ctx **out) {
 }
 
 static void free_graph(dory_ctx *c) {
-    void *ps[] = {c->colPtr, c->rowPtr, c->rowIdx, c->colIdx, c->cscVal, c->csrVal, c->norm, c->orderIn, c->orderOut};
+    void *ps[] = {c->colPtr, c->rowPtr, c->rowIdx, c->colIdx, c->cscVal, c->csrVal, c->norm, c->orderIn, c->orderOut,
+                  c->splitIn, c->splitOut};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     c->colPtr = c->rowPtr = nullptr;
     c->rowIdx = c->colIdx = nullptr;
     c->cscVal = c->csrVal = c->norm = nullptr;
     c->orderIn = c->orderOut = nullptr;
+    c->splitIn = c->splitOut = nullptr;
+    c->nIntIn = c->nIntOut = 0;
     for (LongRowsDev *L : {&c->longIn, &c->longOut}) {
         if (L->rows) (void)hipFree(L->rows);
         if (L->row_chunk_ptr) (void)hipFree(L->row_chunk_ptr);
@@ -311,6 +314,20 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
     if ((rc = upload_array(c, &c->orderIn, oi.data(), (uint64_t)N))) return rc;
     if ((rc = upload_array(c, &c->orderOut, oo.data(), (uint64_t)N))) return rc;
+    for (int d = 0; d < 2 && (d == 0 ? Gsrc : Gdst) > 0; ++d) {   // K1's interior / boundary row split (partitions with ghosts)
+        const uint64_t *ptr = d == 0 ? column_ptrs : row_ptrs;
+        const uint32_t *idx = d == 0 ? row_idxs : column_idxs;
+        const std::vector<uint32_t> &ord = d == 0 ? oi : oo;
+        std::vector<uint32_t> interior, boundary;
+        for (uint32_t v : ord) {   // keeps the longest-row-first order inside both parts
+            bool local = true;
+            for (uint64_t e = ptr[v]; e < ptr[v + 1] && local; ++e) local = idx[e] < N;
+            (local ? interior : boundary).push_back(v);
+        }
+        (d == 0 ? c->nIntIn : c->nIntOut) = (uint32_t)interior.size();
+        interior.insert(interior.end(), boundary.begin(), boundary.end());
+        if ((rc = upload_array(c, d == 0 ? &c->splitIn : &c->splitOut, interior.data(), (uint64_t)N))) return rc;
+    }
     for (int d = 0; d < 2; ++d) {   // K1's hub rows (spmm.hip: long rows)
         LongRowsHost h;
         plan_long_rows(d == 0 ? column_ptrs : row_ptrs, N, &h);

@@ -104,17 +104,35 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         }
     }
     if (!val) return fail(c, DORY_ERR_ARG, "spmm: no edge values");
-    {
-        int rc = wait_halo(c);
-        if (rc) return rc;
-    }
     const LongRowsDev &longRows = csc ? c->longIn : c->longOut;
     if (longRows.nchunks) {   // hubs: K1 stops after LONG_ROW_CLAMP edges of a row, workgroup-per-chunk kernels do the rest
         int rc = ensure_scratch(c, (size_t)longRows.nchunks * a.ld * sizeof(float));
         if (rc) return rc;
         a.row_clamp = LONG_ROW_CLAMP;
     }
+    // K1 under an exchange in flight: the rows whose sources are all local do not depend on it -- they run first, the
+    // rows that read ghost rows after the comm stream's event (what the local-source blocks are for K1b)
+    uint32_t *split = csc ? c->splitIn : c->splitOut;
+    const uint32_t nInt = csc ? c->nIntIn : c->nIntOut;
+    const bool split_rows = (c->halo_pending || c->opt["spmm_blk_force_split"]) && split && nInt > 0 && nInt < c->N &&
+                            !longRows.nchunks;
     Timed t(c, "spmm", c->compute);
+    if (split_rows) {
+        SpmmArgs part = a;
+        part.order = split;
+        part.rows = nInt;
+        HIPCK(c, launch_spmm(part, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+        int rc = wait_halo(c);
+        if (rc) return rc;
+        part.order = split + nInt;
+        part.rows = c->N - nInt;
+        HIPCK(c, launch_spmm(part, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+        return DORY_OK;
+    }
+    {
+        int rc = wait_halo(c);
+        if (rc) return rc;
+    }
     HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
     if (longRows.nchunks) HIPCK(c, launch_spmm_long_rows(a, longRows, c->scratch, c->compute));
     return DORY_OK;

@@ -105,6 +105,10 @@ struct dory_ctx {
     float *cscVal = nullptr, *csrVal = nullptr, *norm = nullptr;
     // longest-row-first schedules for the SpMM (built at upload)
     uint32_t *orderIn = nullptr, *orderOut = nullptr;
+    // K1 under a halo exchange in flight: rows whose sources are all local ("interior", first nInt entries) run
+    // first, the rows that read ghost rows after the exchange; both parts longest row first
+    uint32_t *splitIn = nullptr, *splitOut = nullptr;   // N entries: interior rows, then boundary rows
+    uint32_t nIntIn = 0, nIntOut = 0;
     dory::LongRowsDev longIn, longOut;          // K1: hub rows of forwardAdj / backwardAdj
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
@@ -174,6 +178,7 @@ struct SpmmArgs {
     float *out;             // N x ld
     int accumulate;         // 1: out += result (GAT backward second pass)
     uint32_t row_clamp;     // K1: edges of a row beyond this many are left to the long-row kernels (0 = no limit)
+    uint32_t rows;          // K1: rows of this launch = the first `rows` entries of `order` (0 = all N rows)
     const uint32_t *order;  // optional row schedule (longest first) or nullptr
 };
 hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     const int li = lane % GROUP;
     const int gi = lane / GROUP;
     const uint32_t rid = blockIdx.x * RPB + wave * RPW + gi;
-    const bool row_ok = rid < a.N;
+    const bool row_ok = rid < (a.rows ? a.rows : a.N);   // a.rows: a prefix of the row schedule (interior / boundary split)
     uint32_t v = row_ok ? (a.order ? a.order[rid] : rid) : 0;
     if constexpr (GROUP == 64)  // one row per wave: make it provably wave-uniform (scalar loads, SGPR row base)
         v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -152,8 +152,9 @@ template <int GROUP, int CHUNKS>
 static hipError_t launch_t(const SpmmArgs &a, hipStream_t s) {
     constexpr int RPB = 4 * (64 / GROUP);
     const uint32_t nchunk = a.ld >> 2;
-    dim3 grid((a.N + RPB - 1) / RPB, (nchunk + GROUP * CHUNKS - 1) / (GROUP * CHUNKS));
-    if (a.N == 0 || nchunk == 0) return hipSuccess;
+    const uint32_t rows = a.rows ? a.rows : a.N;
+    dim3 grid((rows + RPB - 1) / RPB, (nchunk + GROUP * CHUNKS - 1) / (GROUP * CHUNKS));
+    if (rows == 0 || nchunk == 0) return hipSuccess;
     hipLaunchKernelGGL((spmm_rows_kernel<GROUP, CHUNKS>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }

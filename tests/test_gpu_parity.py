@@ -48,12 +48,19 @@ def test_aggregate_gcn_forward_backward_vs_oracle(da, case, F):
         ctx.upload(1, "grad", gr)
         ctx.upload(0, "bg", bg)
         ctx.set_option("spmm_variant", 0)
+        # interior rows first, boundary rows in a second launch (what K1 does under an exchange in flight): same bits
+        ctx.set_option("spmm_blk_force_split", 1)
+        ctx.aggregate(0, da.FORWARD)
+        ctx.aggregate(1, da.BACKWARD)
+        split_out = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
+        ctx.set_option("spmm_blk_force_split", 0)
         for order in (1, 0):
             ctx.set_option("spmm_order", order)
             ctx.aggregate(0, da.FORWARD)
             ctx.aggregate(1, da.BACKWARD)
             ah = ctx.download(0, "ah")
             aTg = ctx.download(0, "aTg")
+            assert np.array_equal(ah, split_out[0]) and np.array_equal(aTg, split_out[1])
             ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
             ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
             assert rel_err(ah, ref_f) < 1e-5, (case, r, F, order)
