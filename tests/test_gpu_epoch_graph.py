@@ -29,7 +29,7 @@ def _setup(da, gnn, dims, heads=None, V=2708, E=5278, seed=5):
 
 def _state(ctx, da, gnn, L):
     out = {}
-    names = {da.GCN: ["ah", "z", "h", "grad", "aTg"], da.GAT: ["z", "ah", "h", "grad", "aTg"],
+    names = {da.GCN: ["z", "h", "grad", "aTg", "g"], da.GAT: ["z", "ah", "h", "grad", "aTg"],
              da.GATMH: ["z", "o", "dz", "el", "t"]}[gnn]
     for l in range(L):
         out[("w", l)] = ctx.weight_get(l, "w")
@@ -42,16 +42,18 @@ def _state(ctx, da, gnn, L):
     return out
 
 
-@pytest.mark.parametrize("which", ["gcn", "gat", "gatmh"])
+@pytest.mark.parametrize("which", ["gcn", "gcn_tf", "gat", "gatmh"])
 def test_replayed_epochs_are_bit_identical_to_eager(which):
     import dorylus_amd as da
-    gnn = {"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[which]
+    gnn = {"gcn": da.GCN, "gcn_tf": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[which]
     dims = [1433, 16, 7] if which != "gatmh" else [1433, 32, 7]
     heads = [4, 1] if which == "gatmh" else None
     EPOCHS = 6
     states, times = [], []
     for graph in (0, 1):
         ctx = _setup(da, gnn, dims, heads)
+        if which == "gcn_tf":
+            ctx.set_option("gcn_transform_first", 2)      # the recorded epoch follows the transform-first stage order
         ctx.set_option("epoch_graph", graph)
         eng = da.NativeEngine(ctx)
         ms = eng.run(EPOCHS)          # graph: 1 eager epoch, then record once and replay 5 times
