@@ -154,7 +154,9 @@ int dory_create(int device, dory_ctx **out) {
     }
     (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
     c->own_compute = c->own_comm = true;
-    c->opt["spmm_variant"] = 1;      // 1: K1b source-blocked L2-resident gather where it applies, 0: K1 only
+    c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
+    c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
+    c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
@@ -459,7 +461,7 @@ int dory_preallocate(dory_ctx *c) {
     }
     c->adam.epochs = 1;
     HIPCK(c, hipStreamSynchronize(c->compute));
-    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_blocked"]) {
+    if (c->opt["spmm_variant"] >= 1 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_blocked"]) {
         // the extension's forward sum gathers through the same source-blocked copy of the in-edges
         uint32_t maxld = 0;
         for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
@@ -475,7 +477,7 @@ int dory_preallocate(dory_ctx *c) {
             c->partial_bytes = need;
         }
     }
-    if (c->opt["spmm_variant"] == 1 && N > 0 && c->gnn != DORY_GATMH) {   // K1b: regroup the edges now, not inside the first epoch
+    if (c->opt["spmm_variant"] >= 1 && N > 0 && c->gnn != DORY_GATMH) {   // K1b: regroup the edges now, not inside the first epoch
         uint32_t minld = 0xFFFFFFFFu;
         for (uint32_t l = 0; l < L; ++l) {
             const uint32_t w = c->gnn == DORY_GCN ? (l == 0 ? d[0] : d[l]) : d[l + 1];
@@ -489,7 +491,13 @@ int dory_preallocate(dory_ctx *c) {
             if ((rc = ensure_blocked(c, false, group))) return rc;
             // the partial-sum buffer too, so that no allocation happens inside an epoch
             const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
-            const size_t need = (size_t)nbmax * N * maxld * sizeof(float);
+            size_t need = (size_t)nbmax * N * maxld * sizeof(float);
+            if (c->opt["spmm_variant"] == 2 && nbmax && !c->blkIn.nchunks && !c->blkOut.nchunks) {
+                // K1s keeps its sums in registers: only the gate counters of the largest launch
+                SpmmArgs sa{};
+                sa.N = N; sa.ld = maxld;
+                need = sweep_scratch_bytes(sa, group, std::min<uint32_t>(32u, c->cus_per_xcd), nbmax);
+            }
             if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
                 if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;

@@ -22,7 +22,9 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         // K1b pays nb partial rows per output row: only worth it (and only affordable: the
         // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
         // hundred L2 windows at most.  Larger partitions keep K1.
-        const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u);
+        // K1s (spmm_variant 2) wants two windows in one 4 MB L2; K1b and the multi-head GAT kernels were tuned on ~5 MB
+        const uint64_t window = (c->opt["spmm_variant"] == 2 && c->gnn != DORY_GATMH) ? (uint64_t)c->opt["spmm_sweep_window_kb"] << 10 : 0;
+        const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u, window);
         // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
         // K1 then gathers from L2 without partial sums or a second kernel
         // (a partitioned multi-head GAT run has no row-wise form that reads ghost rows: it always takes the blocks)
@@ -33,7 +35,7 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
             return DORY_OK;
         }
         HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
-                               c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute));
+                               c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute, window));
         B.row_bytes = (uint32_t)group * 16u;
         built = true;
     }
@@ -66,11 +68,43 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.accumulate = accumulate;
     a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
     const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal
-    if (c->opt["spmm_variant"] == 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+    if (c->opt["spmm_variant"] >= 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
         const int group = blk_group_for(c, a.ld);
         int rc = ensure_blocked(c, csc, group);
         if (rc) return rc;
         BlockedAdj &B = csc ? c->blkIn : c->blkOut;
+        if (c->opt["spmm_variant"] == 2 && !(csc ? c->blkIn_na : c->blkOut_na) && sweep_supported(a, B, group)) {
+            // K1s: register accumulators, every workgroup sweeps all source blocks (spmm.hip).  With ghost rows the blocks
+            // that hold local rows only always run as a launch of their own (they do not depend on an exchange in
+            // flight), so the overlapped and the sequential schedule are the same arithmetic.
+            const uint32_t G = std::min<uint32_t>(32u, c->cus_per_xcd);
+            const uint32_t nb_local = std::min(B.nb, c->N / B.SB);
+            const bool two = a.xg != nullptr && nb_local > 0 && nb_local < B.nb;
+            const size_t need = sweep_scratch_bytes(a, group, G, two ? std::max(nb_local, B.nb - nb_local) : B.nb);
+            if (need > c->partial_bytes) {
+                if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: sweep counters would have to grow while recording");
+                HIPCK(c, hipStreamSynchronize(c->compute));
+                if (c->partial) (void)hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
+            Timed t(c, "spmm", c->compute);
+            uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
+            if (two) {
+                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, nb_local, done, c->compute));
+                if ((rc = wait_halo(c))) return rc;
+                SpmmArgs a2 = a;
+                a2.self_mode = 0;
+                a2.accumulate = 1;
+                HIPCK(c, launch_spmm_sweep(a2, B, group, row_scale, G, nb_local, B.nb, done, c->compute));
+            } else {
+                if ((rc = wait_halo(c))) return rc;
+                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, B.nb, done, c->compute));
+            }
+            return DORY_OK;
+        }
         const size_t need = blocked_partial_bytes(a, B);
         if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
             if (need > c->partial_bytes) {

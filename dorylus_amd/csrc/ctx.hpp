@@ -114,6 +114,7 @@ struct dory_ctx {
     dory::BlockedAdj blkIn, blkOut;
     bool blkIn_built = false, blkOut_built = false;
     bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
+    uint32_t cus_per_xcd = 32;                  // K1s: workgroups per sweep
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
     float *partial = nullptr;
@@ -188,8 +189,8 @@ hipError_t launch_spmm_long_rows(const SpmmArgs &a, const LongRowsDev &L, float 
 
 hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                          uint64_t nnz, uint32_t want_nb /*0 = auto*/, uint32_t row_bytes, BlockedAdj *out,
-                         hipStream_t s);
-uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes);
+                         hipStream_t s, uint64_t window_bytes = 0 /*0 = K1b's windows*/);
+uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes = 0);
 hipError_t launch_spmm_blocked_part(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group, bool unit,
                                     uint32_t b_lo, uint32_t b_hi, hipStream_t s);
 // the long (block,row) segments' remainder added into their partial rows (between the part launches and the reduce)
@@ -198,6 +199,11 @@ hipError_t launch_spmm_blocked_long_segments(const SpmmArgs &a, const BlockedAdj
 hipError_t launch_spmm_blocked_reduce(const SpmmArgs &a, const BlockedAdj &B, const float *partial,
                                       const float *row_scale, hipStream_t s);
 void free_blocked(BlockedAdj *B);
+// K1s: the register-accumulating sweep over the same blocked adjacency (spmm.hip)
+bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
+size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks);
+hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
+                             uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s);
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
                                const float *row_scale /*nullable: unit edge weights, per-row factor*/, hipStream_t s);

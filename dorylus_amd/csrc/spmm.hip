@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, 
 // (profiles/r01_k1b_param_sweep.txt) is ~3.7 MB at 256-B rows and ~5 MB at 512-B rows -- a
 // little over the 4 MB L2 is fine (Infinity Cache backs it), shorter (block,row) segments
 // and more partial traffic are not.
-uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes) {
-    const uint64_t window = row_bytes >= 512 ? (uint64_t)5242880u : (uint64_t)3932160u;
+uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes) {
+    const uint64_t window = window_bytes ? window_bytes : row_bytes >= 512 ? (uint64_t)5242880u : (uint64_t)3932160u;
     uint32_t nb = 8;
     if (want_nb) nb = (want_nb + 7) / 8 * 8;
     else while ((uint64_t)((NG + nb - 1) / nb) * row_bytes > window && nb < (1u << 20)) nb += 8;
@@ -374,10 +374,11 @@ uint32_t plan_blocks(uint32_t NG, uint32_t want_nb, uint32_t row_bytes) {
 }
 
 hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
-                         uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, BlockedAdj *out, hipStream_t s) {
+                         uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, BlockedAdj *out, hipStream_t s,
+                         uint64_t window_bytes) {
     BlockedAdj B{};
     if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
-    const uint32_t nb = plan_blocks(NG, want_nb, row_bytes);
+    const uint32_t nb = plan_blocks(NG, want_nb, row_bytes, window_bytes);
     B.nb = nb;
     B.SB = (NG + nb - 1) / nb;
     uint32_t *cnt = nullptr;
@@ -709,6 +710,310 @@ hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *pa
     hipError_t e = launch_spmm_blocked_part(a, B, partial, group, row_scale != nullptr, 0, B.nb, s);
     if (e != hipSuccess) return e;
     return launch_spmm_blocked_reduce(a, B, partial, row_scale, s);
+}
+
+
+// =======================================================================================
+// K1s: "sweep" -- K1b's blocked adjacency without the partial rows.
+//
+// K1b launches one short workgroup per (tile, source block), so a partial row slab is written per block and a second
+// kernel adds them up (27 GB of extra traffic per F=602 launch at Reddit scale, ~5 of 19 ms), and its windows have to be
+// ~5 MB to keep the (block,row) segments long.  What the hardware can do with an L2-resident window is 30-32 TB/s
+// (tools/probes/gather_probe.hip: any lanes/row, any depth; 27.5 at 4 MB, 24.8 at 5 MB, 14.9 at 8 MB).  K1s keeps the
+// sums in registers instead:
+//   * the destination rows are split over the XCDs (workgroup id -> XCD id & 7, for speed only); one 1024-thread
+//     workgroup per CU owns NGRP*R consecutive rows of one feature slab (R rows per lane group, float4 accumulators)
+//     and sweeps ALL source blocks b = 0..nb-1 in order; out = self + sum is written once, no partial buffer, no reduce;
+//   * all workgroups that run on an XCD at the same time must be at (nearly) the same block for the window to be
+//     L2-resident.  They are not by themselves (measured: unsynchronised sweeps gather at the L2-miss rate, 7.5 TB/s),
+//     so a "sweep" = the G workgroups that are resident on an XCD together (G = CUs per XCD) is kept in step by a cheap
+//     gate: a workgroup starts step b when every workgroup of its sweep has finished step b-2 (two windows live).  An
+//     arrival is one L2-local atomic add into the workgroup's own word of a 128-B line per (sweep, step); the first
+//     wave of a workgroup to reach a gate polls that line (8 x 16-B loads that bypass L1), the others watch LDS.
+//     ~1.1 us per step (tools/probes/sync_probe.hip).  Polling is bounded and placement is only assumed, never
+//     required: if the counters do not fill (workgroups placed otherwise, fewer resident than assumed) one timeout
+//     switches the gates off for the launch and the kernel finishes at the unsynchronised rate -- same results;
+//   * per step and lane group the R rows' segments are contiguous in the blocked copy: one coalesced load stages their
+//     (idx,val) pairs in LDS (the next step's offsets and entries are already in flight across the gate), then every row
+//     runs full batches of 4 gathers (nothing predicated) and one predicated tail.
+// Summation order: block order, edge order inside a block -- exactly K1b's, so results agree with K1b to the last
+// reassociation.  A partition with ghost rows always runs as two launches (local-source blocks, then the blocks that
+// contain ghost rows with out += sum) so that the schedule that overlaps the halo exchange and the sequential one
+// are the same arithmetic.  Measured at Reddit scale (tools/probes/spmm_lab.hip): F=602 14.2 ms (K1b 19.1), F=128
+// 2.9 ms (3.9).  Hub (block,row) segments (B.nchunks != 0) keep K1b.
+// =======================================================================================
+constexpr int SWEEP_NT = 1024;
+constexpr int SWEEP_C = 128;             // staged (idx,val) pairs per lane group and pass
+constexpr int SWEEP_U = 4;               // gathers per batch
+constexpr int SWEEP_SLACK = 1;           // start step b when all finished b - SWEEP_SLACK - 1
+constexpr uint32_t SWEEP_SPIN_LIMIT = 20000;
+
+struct SweepArgs {
+    uint32_t rpx;        // destination rows per XCD
+    uint32_t tiles_x;    // workgroups per XCD and slab
+    uint32_t G;          // workgroups per sweep (= CUs per XCD)
+    uint32_t nsweeps;    // slabs * ceil(tiles_x / G)
+    uint32_t b_lo, b_hi; // source blocks of this launch
+    uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
+};
+
+template <int GROUP, int R, bool UNIT, bool GH>
+__global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
+                                                              SweepArgs w) {
+    constexpr int GPW = 64 / GROUP;
+    constexpr int NGRP = SWEEP_NT / GROUP;
+    constexpr int NW = SWEEP_NT / 64;
+    constexpr int RW = NGRP * R;
+    constexpr int C = SWEEP_C, U = SWEEP_U, CQ = C / GROUP;
+    __shared__ uint2 stage[NGRP][C];
+    __shared__ uint32_t o_lds[NGRP][R + 2];
+    __shared__ uint32_t lds_allowed, lds_lock, lds_cnt[8];
+    if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 8) lds_allowed = 0;
+    if (threadIdx.x == 9) lds_lock = 0;
+    __syncthreads();
+    const uint32_t id = blockIdx.x, xcd = id & 7u, k = id >> 3;
+    const uint32_t spp = (w.tiles_x + w.G - 1) / w.G;        // sweeps per slab
+    const uint32_t tiles_pad = spp * w.G;
+    const uint32_t slab = k / tiles_pad, t = k % tiles_pad;
+    if (t >= w.tiles_x) return;                              // padding workgroup of a slab's last sweep
+    const uint32_t q = k / w.G;                              // sweep, global over the slabs
+    const uint32_t cnt_q = min(w.G, w.tiles_x - (q % spp) * w.G);
+    const uint32_t cnt_p = q % spp == 0 ? min(w.G, w.tiles_x - (spp - 1) * w.G) : w.G;   // size of sweep q-1
+    const uint32_t nbs = w.b_hi - w.b_lo;
+    uint32_t *dq = w.done + ((size_t)xcd * w.nsweeps + q) * nbs * 32;
+    uint32_t *gates_off = w.done + (size_t)8 * w.nsweeps * nbs * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % GROUP, gi = lane / GROUP;
+    const int g = wave * GPW + gi;
+    const uint32_t xend = min((xcd + 1) * w.rpx, a.N);
+    const uint32_t v0 = min(xcd * w.rpx + t * RW + (uint32_t)g * R, xend);
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t col = slab * GROUP + li;
+    const bool col_ok = col < nchunk;
+    const uint32_t ccol = col_ok ? col : 0;
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl) + ccol;
+    const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg) + ccol;
+    uint2 *st = stage[g];
+    uint32_t *ol = o_lds[g];
+    const uint32_t orow = min(v0 + (uint32_t)min(li, R), xend);   // lane li <= R holds the offset of row v0 + li
+
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto rowp = [&](uint32_t sidx) -> const float4 * {
+        return (!GH || sidx < a.N) ? xl4 + (size_t)sidx * nchunk : xg4 + (size_t)(sidx - a.N) * nchunk;
+    };
+    // first pass of a step's entries: [o_0, min(o_0 + C, o_R)) of this group, one coalesced load per 32 entries
+    auto load_entries = [&](uint32_t b, uint32_t my_o, uint2 (&en)[CQ]) {
+        const uint64_t base = B.bbase[b];
+        const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
+#pragma unroll
+        for (int qq = 0; qq < CQ; ++qq) {
+            const uint32_t p = o0 + qq * GROUP + li;
+            en[qq] = make_uint2(0u, 0u);
+            if (p < oR) {
+                en[qq].x = __builtin_nontemporal_load(B.bidx + base + p);
+                if constexpr (!UNIT) en[qq].y = __float_as_uint(__builtin_nontemporal_load(B.bval + base + p));
+            }
+        }
+    };
+
+    uint32_t my_o = (B.boff + (size_t)w.b_lo * (a.N + 1))[orow];
+    uint2 en_pre[CQ];
+    load_entries(w.b_lo, my_o, en_pre);
+
+    for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
+        const uint32_t sb = b - w.b_lo;                      // step of this launch
+        {   // gate
+            const int bb = (int)sb - SWEEP_SLACK - 1;
+            const uint32_t *word = bb >= 0 ? dq + (size_t)bb * 32
+                                           : (q > 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
+            const uint32_t need = bb >= 0 ? cnt_q : cnt_p;
+            if (word && (int)nbs + bb >= 0 && lane == 0) {
+                while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sb) {
+                    if (__hip_atomic_exchange(&lds_lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                        uint32_t spins = 0;      // this wave polls for the workgroup
+                        while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sb) {
+                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                            uint32_t sum = 0;
+#pragma unroll
+                            for (int i = 0; i < 32; i += 4) {
+                                u4 v;
+                                const uint32_t *p = word + i;
+                                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+                                sum += v.x + v.y + v.z + v.w;
+                            }
+                            if (sum >= need || __hip_atomic_load(gates_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                            __builtin_amdgcn_s_sleep(4);
+                            if (++spins > SWEEP_SPIN_LIMIT) {
+                                __hip_atomic_store(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        __hip_atomic_store(&lds_allowed, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&lds_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+        }
+        // offsets of the next step (in flight during this one)
+        uint32_t my_o_next = 0;
+        if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (a.N + 1))[orow];
+        if (li <= R) ol[li] = my_o;
+        const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
+        const uint64_t base = B.bbase[b];
+        for (uint32_t cs = o0; cs < oR; cs += C) {
+            const uint32_t ce = min(cs + C, oR);
+            if (cs == o0) {
+#pragma unroll
+                for (int qq = 0; qq < CQ; ++qq)
+                    if (cs + qq * GROUP + li < ce) st[qq * GROUP + li] = en_pre[qq];
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < CQ; ++qq) {
+                    const uint32_t p = cs + qq * GROUP + li;
+                    if (p < ce) {
+                        uint2 en = make_uint2(__builtin_nontemporal_load(B.bidx + base + p), 0u);
+                        if constexpr (!UNIT) en.y = __float_as_uint(__builtin_nontemporal_load(B.bval + base + p));
+                        st[qq * GROUP + li] = en;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t rlo = ol[r], rhi = ol[r + 1];
+                if (B.seg_clamp && rhi - rlo > B.seg_clamp) rhi = rlo + B.seg_clamp;   // (not reached: hub graphs keep K1b)
+                const uint32_t lo = max(rlo, cs), hi = min(rhi, ce);
+                uint32_t e = lo;
+                for (; e + U <= hi; e += U) {               // full batches: nothing predicated
+                    uint2 en[U];
+                    float4 x[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x[u] = *rowp(en[u].x);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[r] = fma4(UNIT ? 1.f : __uint_as_float(en[u].y), x[u], acc[r]);
+                }
+                if (e < hi) {                                // tail: 1 .. U-1 edges
+                    const uint32_t n = hi - e;
+                    uint2 en[U - 1];
+                    float4 x[U - 1];
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) en[u] = st[min(e + u, hi - 1) - cs];
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u)
+                        x[u] = (uint32_t)u < n ? *rowp(en[u].x) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u)
+                        acc[r] = fma4((uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f, x[u], acc[r]);
+                }
+            }
+        }
+        // first pass of the next step's entries: in flight across the gate
+        my_o = my_o_next;
+        if (b + 1 < w.b_hi) load_entries(b + 1, my_o, en_pre);
+        if (lane == 0) {   // the last wave to finish the step reports it for the workgroup
+            const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == NW - 1) {
+                __hip_atomic_store(&lds_cnt[sb & 7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dq + (size_t)sb * 32 + (t & 31), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+
+    float4 *out4 = reinterpret_cast<float4 *>(a.out);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t v = v0 + r;
+        if (v < xend && col_ok) {
+            float4 o4 = acc[r];
+            if (row_scale) {
+                const float rs = row_scale[v];
+                o4 = make_float4(o4.x * rs, o4.y * rs, o4.z * rs, o4.w * rs);
+            }
+            if (a.self_mode != 0) {
+                const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+                o4 = fma4(sc, xl4[(size_t)v * nchunk], o4);
+            }
+            if (a.accumulate) {
+                const float4 p = out4[(size_t)v * nchunk + col];
+                o4.x += p.x; o4.y += p.y; o4.z += p.z; o4.w += p.w;
+            }
+            out4[(size_t)v * nchunk + col] = o4;
+        }
+    }
+}
+
+// rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab
+static int sweep_pick_r(uint32_t N, int group, uint32_t G) {
+    const uint32_t rpx = (N + 7) / 8;
+    int best = 8;
+    double best_fill = 0;
+    for (int R : {10, 8, 6}) {
+        if (group == 16 && R == 10) continue;   // 16-lane groups stage twice the entries per lane: 10 rows would spill
+        const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
+        const uint32_t tiles = (rpx + RW - 1) / RW;
+        const uint32_t spp = (tiles + G - 1) / G;
+        const double fill = (double)rpx / ((double)spp * G * RW);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = R; }
+    }
+    return best;
+}
+
+bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
+    return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8;
+}
+
+// counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
+size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks) {
+    const int R = sweep_pick_r(a.N, group, G);
+    const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
+    const uint32_t rpx = (a.N + 7) / 8, tiles = (rpx + RW - 1) / RW, spp = (tiles + G - 1) / G;
+    const uint32_t slabs = ((a.ld >> 2) + group - 1) / group;
+    return ((size_t)8 * slabs * spp * nblocks * 32 + 1) * sizeof(uint32_t);
+}
+
+// out (+)= self + (row_scale *) sum over source blocks [b_lo, b_hi); `done` = sweep_scratch_bytes() of device memory
+hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
+                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s) {
+    if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
+    if (!sweep_supported(a, B, group) || b_hi > B.nb || G == 0 || G > 32) return hipErrorInvalidValue;
+    const int R = sweep_pick_r(a.N, group, G);
+    SweepArgs w{};
+    const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
+    w.rpx = (a.N + 7) / 8;
+    w.tiles_x = (w.rpx + RW - 1) / RW;
+    w.G = G;
+    const uint32_t spp = (w.tiles_x + G - 1) / G;
+    const uint32_t slabs = ((a.ld >> 2) + group - 1) / group;
+    w.nsweeps = slabs * spp;
+    w.b_lo = b_lo; w.b_hi = b_hi;
+    w.done = done;
+    hipError_t e = hipMemsetAsync(done, 0, sweep_scratch_bytes(a, group, G, b_hi - b_lo), s);
+    if (e != hipSuccess) return e;
+    const dim3 gr(8u * slabs * spp * G), bl(SWEEP_NT);
+    const bool gh = a.xg != nullptr, unit = row_scale != nullptr;
+#define SWEEP_LAUNCH(GRP, RR)                                                                                          \
+    do {                                                                                                               \
+        if (unit) { if (gh) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true>), gr, bl, 0, s, a, B, row_scale, w);   \
+                    else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, false>), gr, bl, 0, s, a, B, row_scale, w); }   \
+        else { if (gh) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, true>), gr, bl, 0, s, a, B, row_scale, w);       \
+               else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, false>), gr, bl, 0, s, a, B, row_scale, w); }       \
+    } while (0)
+#define SWEEP_LAUNCH_R(GRP)                                                                                            \
+    do {                                                                                                               \
+        if (R == 8) SWEEP_LAUNCH(GRP, 8); else SWEEP_LAUNCH(GRP, 6);                                                   \
+    } while (0)
+    if (group == 32) { if (R == 10) SWEEP_LAUNCH(32, 10); else SWEEP_LAUNCH_R(32); }
+    else SWEEP_LAUNCH_R(16);
+#undef SWEEP_LAUNCH_R
+#undef SWEEP_LAUNCH
+    return hipGetLastError();
 }
 
 }  // namespace dory

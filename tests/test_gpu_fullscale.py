@@ -57,32 +57,33 @@ def test_fullscale_aggregate_properties(reddit, F):
     X = ctx.download(0, "x")
     G = ctx.download(1, "grad")
     outs = {}
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         ctx.set_option("spmm_variant", variant)
         ctx.aggregate(0, da.FORWARD)
         ctx.aggregate(1, da.BACKWARD)
         outs[variant] = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
-    # K1 vs K1b
+    # K1 vs K1b vs K1s (the sweep: same block order as K1b, no partial rows)
     assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and rel_err(outs[1][1], outs[0][1]) < 1e-5
+    assert rel_err(outs[2][0], outs[0][0]) < 1e-5 and rel_err(outs[2][1], outs[0][1]) < 1e-5
     # sampled rows vs oracle (highest-degree rows included)
     rng = np.random.default_rng(0)
     deg = np.diff(g["colPtr"].astype(np.int64))
     rows = np.unique(np.concatenate([rng.integers(0, N, 2000), np.argsort(deg)[-20:], [0, N - 1]]))
     ref = _oracle_rows(g, "colPtr", "rowIdx", "cscVal", X, rows)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         assert rel_err(outs[variant][0][rows], ref) < 1e-4
     refb = _oracle_rows(g, "rowPtr", "colIdx", "csrVal", G, rows)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         assert rel_err(outs[variant][1][rows], refb) < 1e-4
     # checksum of checksums in float64
     w = g["norm"].astype(np.float64) + np.bincount(g["rowIdx"], weights=g["cscVal"].astype(np.float64), minlength=N)
     expect = w @ X.astype(np.float64)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         got = outs[variant][0].astype(np.float64).sum(0)
         assert np.abs(got - expect).max() / np.abs(expect).max() < 1e-5
     # scale covariance, bit-exact
     ctx.upload(0, "x", X * np.float32(2.0))
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         ctx.set_option("spmm_variant", variant)
         ctx.aggregate(0, da.FORWARD)
         assert np.array_equal(ctx.download(0, "ah"), outs[variant][0] * np.float32(2.0))
@@ -242,7 +243,7 @@ def test_fullscale_gat_prototype_fast_path_vs_general(reddit):
     from helpers import rel_err
     N = int(g["localVtxCnt"])
     res = {}
-    for variant in (1, 0):
+    for variant in (2, 1, 0):
         ctx = da.Context(0)
         ctx.configure(da.GAT, [602, 128, 41], N)
         ctx.set_option("spmm_variant", variant)
@@ -264,3 +265,5 @@ def test_fullscale_gat_prototype_fast_path_vs_general(reddit):
         # aTg a sum of large terms of both signs, summed in edge order by K1 and in block order by K1b
         tol = 1e-4 if k[0] in ("z", "ah") else 2e-3
         assert rel_err(res[1][k], res[0][k]) < tol, (k, rel_err(res[1][k], res[0][k]))
+        # K1s sums block by block like K1b (with other block boundaries): same bar
+        assert rel_err(res[2][k], res[0][k]) < tol, (k, rel_err(res[2][k], res[0][k]))

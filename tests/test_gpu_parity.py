@@ -98,6 +98,94 @@ def test_aggregate_blocked_variant_vs_oracle(da, case, F):
         ctx.close()
 
 
+@pytest.mark.parametrize("F", [41, 128, 602, 1433])
+@pytest.mark.parametrize("case", ["parts_toy60_p1", "parts_toy60_p2", "parts_toy97_p8_und", "parts_toy40_p3_empty"])
+def test_aggregate_sweep_variant_vs_oracle(da, case, F):
+    """K1s (register-accumulating sweep over the blocked adjacency, gated per XCD) == oracle on the reference-built
+    partitions, forward (CSC) and backward (CSR), ghosts included: with ghost rows the local-source blocks and the
+    ghost blocks are two launches (out += sum), with and without an exchange in flight the same bits."""
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, parts = _golden_partitions(case)
+    rng = np.random.default_rng(F + 2)
+    for r, g in enumerate(gs):
+        N = g["localVtxCnt"]
+        ctx = make_ctx(da, g, [F, F, 3], g["globalVtxCnt"], node_id=r, num_nodes=len(gs))
+        ctx.set_option("spmm_variant", 2)
+        x = rng.standard_normal((N, F)).astype(np.float32)
+        fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
+        gr = rng.standard_normal((N, F)).astype(np.float32)
+        bg = rng.standard_normal((g["dstGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
+        ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
+        ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
+        prev = None
+        for grp, nb in ((32, 8), (16, 8), (32, 16), (16, 24)):   # toy graphs: explicit block counts (else K1 takes them)
+            ctx.set_option("spmm_blk_group", grp)
+            ctx.set_option("spmm_blk_nb", nb)
+            for split in (0, 1):
+                ctx.set_option("spmm_blk_force_split", split)
+                ctx.aggregate(0, da.FORWARD)
+                ctx.aggregate(1, da.BACKWARD)
+                got = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
+                assert rel_err(got[0], ref_f) < 1e-5, (case, r, F, grp, nb)
+                assert rel_err(got[1], ref_b) < 1e-5, (case, r, F, grp, nb)
+                if split:
+                    assert np.array_equal(got[0], prev[0]) and np.array_equal(got[1], prev[1])
+                prev = got
+        ctx.close()
+
+
+def test_sweep_variant_several_sweeps_and_unit_weights(da):
+    """K1s on a graph large enough for several sweeps per slab (more workgroup tasks per XCD than CUs), a ragged last
+    sweep, rows that end inside a workgroup, empty rows, F = 128 and 602; and the unit-weight form with a
+    per-destination factor (the reference GAT's aggregation) against the explicit per-edge values through K1."""
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    rng = np.random.default_rng(31)
+    V, E = 90001, 1200000
+    s = rng.integers(0, V, E)
+    d = rng.integers(0, V - 700, E)          # the last 700 vertices have no in-edges
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    for F in (128, 602):
+        ctx = make_ctx(da, g, [F, F, 3], V)
+        x = rng.standard_normal((V, F)).astype(np.float32)
+        gr = rng.standard_normal((V, F)).astype(np.float32)
+        ctx.upload(0, "x", x)
+        ctx.upload(1, "grad", gr)
+        ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
+        ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr)
+        outs = {}
+        for variant, nb in ((2, 0), (2, 40), (1, 0)):
+            ctx.set_option("spmm_variant", variant)
+            ctx.set_option("spmm_blk_nb", nb)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            outs[(variant, nb)] = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
+            assert rel_err(outs[(variant, nb)][0], ref_f) < 1e-5, (F, variant, nb)
+            assert rel_err(outs[(variant, nb)][1], ref_b) < 1e-5, (F, variant, nb)
+        ctx.close()
+    # reference GAT prototype, whole epoch: unit-weight sweep with row factors (default) vs general K1
+    res = {}
+    dims = [64, 128, 16]
+    for variant in (2, 0):
+        ctx = make_ctx(da, g, dims, V, gnn=da.GAT)
+        ctx.set_option("spmm_variant", variant)
+        ctx.fill_uniform(0, "h", 5)
+        ctx.labels_upload((np.arange(V) % dims[-1]).astype(np.uint32))
+        ctx.weights_init_xavier()
+        ctx.adam_config(0.01)
+        eng = da.NativeEngine(ctx)
+        eng.run(1)
+        res[variant] = {(nm, l): ctx.download(l, nm) for l in range(2) for nm in ("z", "ah", "aTg")}
+        eng.close()
+        ctx.close()
+    for k in res[2]:
+        assert np.isfinite(res[2][k]).all(), k
+        assert rel_err(res[2][k], res[0][k]) < (1e-4 if k[0] in ("z", "ah") else 2e-3), k
+
+
 def test_blocked_variant_many_blocks(da):
     """enough source rows for several rounds of 8 blocks (nb = 16+), skewed degrees."""
     import orc
