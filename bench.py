@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--opt", nargs="*", default=[], help="context options key=value (diagnostic runs, e.g. spmm_variant=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra transform-first epochs (profiling runs: only the headline kernels)")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows sampled for the CPU baseline (0 = auto)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="restrict the CPU baseline to the first rows (0 = the full epoch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -270,18 +270,26 @@ def main():
     launches_per_epoch = 3
     avg_launch_ms = spmm_ms / max(spmm_n, 1)
     achieved = (algo / launches_per_epoch) / (avg_launch_ms * 1e-3) / 1e9   # GB/s per average launch
-    traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+    variant = ctx.get_option("spmm_variant")
+    kernel_name = {2: "spmm_sweep_kernel<32,R,false,false> (K1s: register accumulators, gated per-XCD sweep over the source blocks; one aggregate = one launch)",
+                   1: "spmm_blocked_kernel<32> + spmm_reduce_kernel (K1b; one aggregate = both)",
+                   0: "spmm_rows_kernel<64,3> / <32,1> (K1 row gather)"}.get(variant, "spmm")
+    traffic = None   # HBM-side bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
+    traffic_src = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if world == 1 and args.graph == "uniform" and args.scale == 1.0 and not args.emulate and args.workload == "reddit" and not args.opt:
-            traffic = pm["spmm_variant_1"]["bytes_per_launch"]
+            ent = pm["spmm_variant_%d" % variant]
+            traffic = ent["bytes_per_launch"]
+            traffic_src = ent.get("source")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                "kernel": "spmm_blocked_kernel<32> + spmm_reduce_kernel (K1b; one aggregate = both)", "avg_launch_ms": round(avg_launch_ms, 4),
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 4),
                 "algorithmic_bytes_per_launch": int(algo / launches_per_epoch),
-                "gather_bytes_per_launch": int((2 * nnz_in * 0 + (nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4) / 3)}
+                "gather_bytes_per_launch": int((nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4 / 3),
+                "l2_gather_TBps": round((nnz_in * 608 + nnz_in * 128 + nnz_out * 128) * 4 / 3 / (avg_launch_ms * 1e-3) / 1e12, 2)}
 
     # second kernel family: the dense transforms on fp32 MFMA (all GEMMs of the epoch, split-K stages included)
     gemm_ms, gemm_n = fam["gemm"]
@@ -314,6 +322,26 @@ def main():
                    "aggregation_widths": [DIMS[l + 1] if l in nar else DIMS[l] for l in range(nl)]}
         ctx.set_option("gcn_transform_first", 0)
 
+    # ---- multi-GPU bookkeeping: load balance, halo volume, link rate ----
+    multi = None
+    if world > 1:
+        ld1 = (DIMS[1] + 31) // 32 * 32
+        mine = torch.tensor([nnz_in, N, Gs * ld1 * 4 + Gd * ld1 * 4, fam["halo"][0], fam["allreduce"][0]], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        A = np.array([t.cpu().numpy() for t in allr])
+        halo_ms = A[:, 3] / args.steps
+        multi = {"nnz_in_per_rank_max": int(A[:, 0].max()), "nnz_in_per_rank_mean": float(A[:, 0].mean()),
+                 "nnz_max_over_mean": float(A[:, 0].max() / max(A[:, 0].mean(), 1.0)),
+                 "vertices_per_rank": [int(v) for v in A[:, 1]],
+                 "halo_bytes_received_per_epoch_total": int(A[:, 2].sum()),
+                 "halo_bytes_received_per_epoch_max_rank": int(A[:, 2].max()),
+                 "halo_ms_per_epoch_max_rank": float(halo_ms.max()),
+                 "halo_GBps_per_rank_min": float((A[:, 2] / np.maximum(halo_ms, 1e-9) / 1e6).min()),
+                 "allreduce_ms_per_epoch_max_rank": float((A[:, 4] / args.steps).max()),
+                 "note": "halo = one all-to-all-v of h (forward) and one of grad (backward) per epoch, " + str(DIMS[1]) + " floats per ghost row; "
+                         "ms are HIP-event times on the comm stream (pack + grouped ncclSend/ncclRecv + unpack), overlapped with the interior-source SpMM blocks"}
+
     if gat or tf_mode or args.workload != "reddit":   # the roofline bookkeeping above is for the Reddit GCN epoch's three launches
         roofline = None
         roofline_gemm = None
@@ -341,14 +369,68 @@ def main():
             "transform_first": alt,
             "cpu_baseline": cpu,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
-            "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1),
+            "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1), "multi_gpu": multi,
             "setup_s": round(t_setup, 1),
         }
-        print(json.dumps(out), flush=True)
     eng.close()
     ctx.close()
+    # ---- the other single-GPU configurations, each timed the same way (extra keys beside the headline) ----
+    if rank == 0 and world == 1 and not gat and not tf_mode and not args.emulate and not args.opt and not args.no_alt \
+            and args.workload == "reddit" and args.graph == "uniform" and args.scale == 1.0:
+        steps_x, warm_x = max(2, min(args.steps, 5)), 1
+        out["gatmh"] = extra_epoch(da, part, g, "gatmh", V, steps_x, warm_x,
+                                   "BASELINE config 3 wording: Reddit GAT 2-layer 8-head, per-edge attention softmax + weighted sum "
+                                   "(extension, parity unpinned: the reference has no such kernel), same uniform graph")
+        out["gat"] = extra_epoch(da, part, g, "gat", V, steps_x, warm_x,
+                                 "BASELINE config 3, reference GAT prototype (single head, per-destination edge score), same uniform graph")
+        del part
+        src, dst = synth_edges("rmat", V, E_target)
+        part_r = da.Partition.build(src, dst, np.zeros(V, np.int32), 0, 1)
+        del src, dst
+        out["rmat"] = extra_epoch(da, part_r, part_r.view(), "gcn", V, steps_x, warm_x,
+                                  "same GCN epoch on an R-MAT graph (a=.57 b=.19 c=.19, SURVEY 8d): same V and E, max degree ~8e5")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_epoch(da, part, g, gnn, V, steps, warmup, what):
+    """one more configuration on one GPU: fresh context, same epoch loop, K timed steps after W warm-up steps"""
+    import torch
+    N = int(g["localVtxCnt"])
+    ctx = da.Context(0)
+    gat = gnn in ("gat", "gatmh")
+    ctx.configure({"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[gnn], DIMS, V, 0, 1)
+    if gnn == "gatmh":
+        ctx.gatmh_heads([8, 1])
+    part.upload(ctx, None)
+    ctx.preallocate()
+    ctx.fill_uniform(0, "h" if gat else "x", 1, -1.0, 1.0, g["localToGlobal"])
+    labels = np.random.default_rng(2).integers(0, DIMS[-1], V).astype(np.uint32)
+    ctx.labels_upload(labels[g["localToGlobal"]])
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(warmup)
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(steps)
+    ctx.sync()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    fam = {f: ctx.timing_get(f) for f in ("spmm", "gemm", "loss", "adam")}
+    nnz_in, nnz_out = int(g["localInEdgeCnt"]), int(g["localOutEdgeCnt"])
+    edges = (4 * nnz_in + 2 * nnz_out) if gat else (2 * nnz_in + nnz_out)
+    res = {"what": what, "ms_per_step": ms, "steps": steps, "warmup": warmup, "edges_per_s": edges / (ms * 1e-3),
+           "spmm_variant": ctx.get_option("spmm_variant"),
+           "kernel_ms_per_epoch": {k: round(v[0] / steps, 4) for k, v in fam.items() if v[1]}}
+    eng.close()
+    ctx.close()
+    return res
 
 
 class stdout_to_stderr:
@@ -382,19 +464,21 @@ def usable_cpus():
 
 def cpu_baseline(ctx, g, rows):
     """Times oracle/ (the CPU restatement of the reference's cpu backend: aggregateGCN +
-    CPUComm::vtxNN*GCN) on this box's host cores over a bounded sample of the same
-    epoch: the first `rows` destination vertices with their complete in/out edge
-    lists -- all three aggregations and all five GEMMs + activations for those rows.
-    Source rows outside the sample are taken from the GPU run's tensors (same inputs).
-    Reported, not optimised against."""
+    CPUComm::vtxNN*GCN) on this box's host cores over ONE FULL EPOCH of the same graph and
+    the same inputs the GPU run used: all rows, three aggregations through the per-edge
+    pointer tables of engine/utils.cpp:655-705 (built before the clock starts, as the
+    reference builds them in preallocate), five GEMMs, activations and loss.  OpenMP over
+    vertices with the default (static) schedule like gcn_ops.cpp:159-161, one fixed thread
+    count = the hardware threads this process may use.  `rows` > 0 restricts the epoch to
+    the first `rows` destination rows (diagnostic).  Reported, not optimised against."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     N = int(g["localVtxCnt"])
     V = int(g["globalVtxCnt"])
     ncores = usable_cpus()
-    if rows <= 0:
-        rows = min(N, 40000)
-    rows = min(rows, N)
+    full = rows <= 0 or rows >= N
+    rows = N if full else rows
+    orc.lib.orc_set_threads(ncores)
 
     def sub(ptr_key, idx_key, val_key):
         ptr = np.ascontiguousarray(g[ptr_key][:rows + 1])
@@ -403,49 +487,48 @@ def cpu_baseline(ctx, g, rows):
     cptr, cidx, cval, e_in = sub("colPtr", "rowIdx", "cscVal")
     rptr, ridx, rval, e_out = sub("rowPtr", "colIdx", "csrVal")
     norm = np.ascontiguousarray(g["norm"][:rows])
-    X = ctx.download(0, "x")            # the very inputs / intermediates of the GPU run
-    H = ctx.download(0, "h")
-    G1 = ctx.download(1, "grad")
+    X = np.ascontiguousarray(ctx.download(0, "x"))            # the very inputs / intermediates of the GPU run
+    H = np.ascontiguousarray(ctx.download(0, "h"))
+    G1 = np.ascontiguousarray(ctx.download(1, "grad"))
     lab = ctx.download(1, "lab")[:rows]
     # weights as they were when the last GPU epoch started are gone (Adam stepped);
     # the baseline only needs *a* weight set of the right shape for timing + ah parity
     W0, W1 = ctx.weight_get(0), ctx.weight_get(1)
 
     def agg(ptr, idx, val, Xfull):
+        # pointer table first (not timed: preallocate-time work in the reference), then the timed aggregation
         F = Xfull.shape[1]
-        out = np.empty((rows, F), np.float32)
-        tail = Xfull[rows:] if rows < N else np.zeros((1, F), np.float32)   # "ghost" rows = rest of the buffer
-        orc.lib.orc_aggregate_gcn(rows, F, ptr, idx, val, norm, Xfull[:rows], tail, out)
-        return out
-    # thread count: all hardware threads vs one per physical core -- keep whichever the
-    # memory-bound aggregation runs faster with (the reference just takes OMP defaults)
-    best = None
-    for nt in sorted({ncores, max(1, ncores // 2)}, reverse=True):
-        orc.lib.orc_set_threads(nt)
+        tail = Xfull[rows:] if rows < N else None                 # "ghost" rows = rest of the buffer (sampled runs)
+        eptr, keep = orc.edge_pointers(ptr, idx, Xfull[:rows], tail)
         t0 = time.perf_counter()
-        agg(cptr, cidx, cval, H)
+        out = orc.aggregate_gcn_ptr(ptr, eptr, val, norm, Xfull[:rows])
         dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (nt, dt)
-    ncores = best[0]
-    orc.lib.orc_set_threads(ncores)
-    t = [time.perf_counter()]
-    ah0 = agg(cptr, cidx, cval, X); t.append(time.perf_counter())              # GA  L0 fwd
-    z0, h0 = orc.vtx_forward_hidden(ah0, W0); t.append(time.perf_counter())     # AV  L0 fwd
-    ah1 = agg(cptr, cidx, cval, H); t.append(time.perf_counter())              # GA  L1 fwd
-    last = orc.vtx_forward_last(ah1, W1, lab, V); t.append(time.perf_counter())  # AV  L1 fwd (+loss, grad, dW1)
-    aTg0 = agg(rptr, ridx, rval, G1); t.append(time.perf_counter())            # GA  L1 bwd
-    orc.vtx_backward(aTg0, z0, ah0, W0, 0); t.append(time.perf_counter())       # AV  L0 bwd (dW0)
-    total = t[-1] - t[0]
+        del eptr, keep
+        return out, dt
+    stage = {}
+    ah0, stage["agg_F602"] = agg(cptr, cidx, cval, X)                            # GA  L0 fwd
+    t0 = time.perf_counter()
+    z0, h0 = orc.vtx_forward_hidden(ah0, W0)                                      # AV  L0 fwd
+    stage["transform_L0"] = time.perf_counter() - t0
+    ah1, stage["agg_F128_fwd"] = agg(cptr, cidx, cval, H)                        # GA  L1 fwd
+    t0 = time.perf_counter()
+    orc.vtx_forward_last(ah1, W1, lab, V)                                         # AV  L1 fwd (+loss, grad, dW1)
+    stage["transform_last"] = time.perf_counter() - t0
+    aTg0, stage["agg_F128_bwd"] = agg(rptr, ridx, rval, G1)                      # GA  L1 bwd
+    t0 = time.perf_counter()
+    orc.vtx_backward(aTg0, z0, ah0, W0, 0)                                        # AV  L0 bwd (dW0)
+    stage["transform_bwd"] = time.perf_counter() - t0
+    total = sum(stage.values())
     edges = 2 * e_in + e_out
     gpu_ah0 = ctx.download(0, "ah")[:rows]
     err = float(np.abs(gpu_ah0 - ah0).max() / max(np.abs(ah0).max(), 1e-30))
-    names = ["agg_F602", "transform_L0", "agg_F128_fwd", "transform_last", "agg_F128_bwd", "transform_bwd"]
+    what = "one FULL epoch of the same graph (all %d rows" % rows if full else "one epoch restricted to the first %d destination rows (" % rows
     return {"value": edges / total, "unit": "edges/s", "cores": ncores, "kind": "port",
-            "sample": f"one epoch restricted to the first {rows} destination rows of the same graph "
-                      f"({e_in} in-edges, {e_out} out-edges): 3 aggregations + 5 GEMMs + activations/loss, "
-                      f"{total:.2f} s of CPU time, OpenMP over vertices, {ncores} threads",
-            "stage_s": {n: round(t[i + 1] - t[i], 3) for i, n in enumerate(names)},
+            "sample": f"{what}, {e_in} in-edges, {e_out} out-edges): 3 aggregations through per-edge pointer tables "
+                      f"(engine/utils.cpp:655-705, built outside the clock) + 5 GEMMs + activations/loss, "
+                      f"{total:.2f} s of CPU time = epoch_s, OpenMP static over vertices, {ncores} threads (all this process may use)",
+            "epoch_s": round(total, 3),
+            "stage_s": {n: round(v, 3) for n, v in stage.items()},
             "gpu_vs_oracle_rel_err_ah0": err}
 
 

@@ -36,6 +36,18 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         }
         HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
                                c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute, window));
+        if (window && B.nchunks) {
+            // hub (block,row) segments: K1s does not take them (a long segment on one lane group would hold up every
+            // workgroup of its XCD at the gate); K1b does, with its own window size
+            free_blocked(&B);
+            const uint32_t nb1 = plan_blocks(NG, want_nb, (uint32_t)group * 16u, 0);
+            if (nb1 > 256 || (uint64_t)nb1 * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
+                (csc ? c->blkIn_na : c->blkOut_na) = true;
+                return DORY_OK;
+            }
+            HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
+                                   c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute, 0));
+        }
         B.row_bytes = (uint32_t)group * 16u;
         built = true;
     }

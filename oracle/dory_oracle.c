@@ -79,6 +79,44 @@ void orc_aggregate_gcn(uint32_t N, uint32_t F, const uint64_t *ptr,
 }
 
 /* ------------------------------------------------------------------------
+ * The same aggregation through the reference's per-edge pointer table:
+ * Engine::srcVFeats2eFeats / dstVFeats2eFeats (engine/utils.cpp:655-705) build,
+ * once at preallocate time (gcn_ops.cpp:44-48,72-76), one `FeatType *` per edge
+ * that points at the source vertex's row in the local or the ghost tensor;
+ * aggregateGCN then reads inputTensor[eid][j] (gcn_ops.cpp:174-188): 8 B of
+ * pointer + 4 B of value per edge instead of an index and a select.  This is
+ * the form bench.py times as the CPU baseline.
+ * ---------------------------------------------------------------------- */
+void orc_edge_pointers(uint32_t N, uint32_t F, const uint64_t *ptr,
+                       const uint32_t *idx, const float *x_local,
+                       const float *x_ghost, const float **eptr) {
+#pragma omp parallel for schedule(static)
+    for (uint32_t v = 0; v < N; ++v)
+        for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) { /* utils.cpp:664-675 */
+            const uint32_t s = idx[e];
+            eptr[e] = s < N ? x_local + (size_t)s * F
+                            : x_ghost + (size_t)(s - N) * F;
+        }
+}
+
+void orc_aggregate_gcn_ptr(uint32_t N, uint32_t F, const uint64_t *ptr,
+                           const float *const *eptr, const float *val,
+                           const float *norm, const float *x_local, float *out) {
+    memcpy(out, x_local, sizeof(float) * (size_t)N * F); /* gcn_ops.cpp:155-157 */
+#pragma omp parallel for /* gcn_ops.cpp:159-161: default (static) schedule */
+    for (uint32_t v = 0; v < N; ++v) {
+        float *dst = out + (size_t)v * F;
+        const float nf = norm[v];
+        for (uint32_t i = 0; i < F; ++i) dst[i] *= nf; /* :166-171 */
+        for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) { /* :174-180 / :182-188 */
+            const float w = val[e];
+            const float *src = eptr[e];
+            for (uint32_t j = 0; j < F; ++j) dst[j] += src[j] * w;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
  * Engine::aggregateGAT forward (engine/ops/gat_ops.cpp:201-220):
  *   ah[v,:] = z[v,:] + sum_{in e} A[e]*z_src(e)[:]   (unit self weight)
  * ---------------------------------------------------------------------- */

@@ -22,6 +22,9 @@ _f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32 = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 lib.orc_aggregate_gcn.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f, _f, _f]
+_ptrs = np.ctypeslib.ndpointer(dtype=np.uintp, flags="C_CONTIGUOUS")
+lib.orc_edge_pointers.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _ptrs]
+lib.orc_aggregate_gcn_ptr.argtypes = [C.c_uint32, C.c_uint32, _u64, _ptrs, _f, _f, _f, _f]
 lib.orc_aggregate_gat_fwd.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f, _f]
 lib.orc_aggregate_gat_bwd.argtypes = [C.c_uint32, C.c_uint32, _u64, _u32, _f, _f, _f,
                                       _u64, _u32, _f, _f, _f, _f]
@@ -61,6 +64,22 @@ def aggregate_gcn(ptr, idx, val, norm, x, ghost=None):
     out = np.empty_like(x)
     lib.orc_aggregate_gcn(N, F, _c(ptr, np.uint64), _c(idx, np.uint32), _c(val), _c(norm), x,
                           _ghost(ghost, F), out)
+    return out
+
+
+def edge_pointers(ptr, idx, x, ghost=None):
+    """per-edge source-row pointers (engine/utils.cpp:655-705); `x` and `ghost` must stay alive and unmoved"""
+    N, F = x.shape
+    gh = _c(ghost) if ghost is not None and ghost.size else _ghost(None, F)
+    out = np.empty(int(ptr[-1]), np.uintp)
+    lib.orc_edge_pointers(N, F, _c(ptr, np.uint64), _c(idx, np.uint32), x, gh, out)
+    return out, gh
+
+
+def aggregate_gcn_ptr(ptr, eptr, val, norm, x):
+    N, F = x.shape
+    out = np.empty((N, F), np.float32)
+    lib.orc_aggregate_gcn_ptr(N, F, _c(ptr, np.uint64), eptr, _c(val), _c(norm), x, out)
     return out
 
 
