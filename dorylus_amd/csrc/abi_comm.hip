@@ -268,7 +268,9 @@ static float adam_lr_t(const dory_ctx *c, unsigned epochs) {   // AdamOptimizer:
     return (float)(c->adam.lr * (std::sqrt((double)(1 - b2p))) / (1 - b1p));
 }
 
-static void epoch_graph_drop_locked(dory_ctx *c) {
+}  // extern "C"
+namespace dory {
+void epoch_graph_drop_locked(dory_ctx *c) {
     if (c->capturing) {   // abandon a recording in progress
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(c->compute, &g);
@@ -281,6 +283,9 @@ static void epoch_graph_drop_locked(dory_ctx *c) {
     c->epoch_graph = nullptr;
     c->lr_table_left = 0;
 }
+
+}  // namespace dory
+extern "C" {
 
 int dory_epoch_graph_drop(dory_ctx *c) {
     CHECK_CTX(c);
@@ -336,8 +341,11 @@ int dory_epoch_graph_launch(dory_ctx *c, uint32_t epochs) {
             HIPCK(c, hipStreamSynchronize(c->compute));   // previous replays have read the old table
             c->lr_table_host.resize(c->lr_table_cap);
             for (uint32_t k = 0; k < c->lr_table_cap; ++k) c->lr_table_host[k] = adam_lr_t(c, c->adam.epochs + k);
-            HIPCK(c, hipMemcpy(c->d_lr_table, c->lr_table_host.data(), c->lr_table_cap * sizeof(float), hipMemcpyHostToDevice));
-            HIPCK(c, hipMemset(c->d_replay_idx, 0, sizeof(uint32_t)));
+            // on the replay stream itself: c->compute is a non-blocking stream, the legacy null stream is not ordered
+            // against it (a null-stream memset could still be in flight when the replayed adam_table_kernel reads *idx)
+            HIPCK(c, hipMemcpyAsync(c->d_lr_table, c->lr_table_host.data(), c->lr_table_cap * sizeof(float), hipMemcpyHostToDevice, c->compute));
+            HIPCK(c, hipMemsetAsync(c->d_replay_idx, 0, sizeof(uint32_t), c->compute));
+            HIPCK(c, hipStreamSynchronize(c->compute));   // lr_table_host may be resized again only after the copy
             c->lr_table_left = c->lr_table_cap;
         }
         HIPCK(c, hipGraphLaunch(c->epoch_exec, c->compute));

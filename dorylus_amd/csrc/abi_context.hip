@@ -293,6 +293,7 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     if (!column_ptrs || !row_ptrs || (N && !vtx_norms) || (nnz_in && (!row_idxs || !csc_values)) ||
         (nnz_out && (!column_idxs || !csr_values)))
         return fail(c, DORY_ERR_ARG, "dory_graph_upload: null array");
+    epoch_graph_drop_locked(c);   // a recorded epoch points at the adjacency (and its blocked copies) freed below
     if (column_ptrs[0] != 0 || column_ptrs[N] != nnz_in || row_ptrs[0] != 0 || row_ptrs[N] != nnz_out)
         return fail(c, DORY_ERR_ARG, "dory_graph_upload: pointer arrays do not match nnz");
     for (uint32_t v = 0; v < N; ++v)
@@ -316,7 +317,8 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
     if ((rc = upload_array(c, &c->orderIn, oi.data(), (uint64_t)N))) return rc;
     if ((rc = upload_array(c, &c->orderOut, oo.data(), (uint64_t)N))) return rc;
-    for (int d = 0; d < 2 && (d == 0 ? Gsrc : Gdst) > 0; ++d) {   // K1's interior / boundary row split (partitions with ghosts)
+    for (int d = 0; d < 2; ++d) {   // K1's interior / boundary row split (partitions with ghosts), each direction on its own
+        if ((d == 0 ? Gsrc : Gdst) == 0) continue;
         const uint64_t *ptr = d == 0 ? column_ptrs : row_ptrs;
         const uint32_t *idx = d == 0 ? row_idxs : column_idxs;
         const std::vector<uint32_t> &ord = d == 0 ? oi : oo;
@@ -348,6 +350,7 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
 int dory_preallocate(dory_ctx *c) {
     CHECK_CTX(c);
     if (!c->configured || !c->has_graph) return fail(c, DORY_ERR_ARG, "dory_preallocate: configure and graph_upload first");
+    epoch_graph_drop_locked(c);   // a recorded epoch points at the tensors freed below
     HIPCK(c, hipDeviceSynchronize());
     free_table(c->tensors); free_table(c->weights); free_table(c->wgrads); free_table(c->adam_m); free_table(c->adam_v);
     const uint32_t L = c->L, N = c->N;
@@ -698,6 +701,10 @@ int dory_transform_first_layer(dory_ctx *c, uint32_t layer) {
 
 int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     CHECK_CTX(c);
+    if (key && value && !strcmp(key, "epoch_graph_recorded")) {   // read-only: does the ctx still hold a recorded epoch?
+        *value = c->epoch_exec ? 1 : 0;
+        return DORY_OK;
+    }
     if (!key || !value || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
     *value = c->opt[key];
     return DORY_OK;

@@ -482,6 +482,7 @@ __global__ void scatter_rows_kernel(float *dst, const float *src, uint32_t ld, u
 hipError_t launch_gather_rows(float *dst, const float *src, uint32_t ld, uint32_t cols,
                               const uint32_t *rows, uint32_t n, hipStream_t s) {
     if (n == 0 || cols == 0) return hipSuccess;
+    if ((cols & 3) || (ld & 3)) return hipErrorInvalidValue;   // float4 rows only (every exchanged tensor is padded to 32 floats)
     const uint64_t total = (uint64_t)n * (cols / 4);
     int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, s, dst, src, ld, cols / 4, rows, n);
@@ -490,6 +491,7 @@ hipError_t launch_gather_rows(float *dst, const float *src, uint32_t ld, uint32_
 hipError_t launch_scatter_rows(float *dst, const float *src, uint32_t ld, uint32_t cols,
                                const uint32_t *rows, uint32_t n, hipStream_t s) {
     if (n == 0 || cols == 0) return hipSuccess;
+    if ((cols & 3) || (ld & 3)) return hipErrorInvalidValue;
     const uint64_t total = (uint64_t)n * (cols / 4);
     int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, s, dst, src, ld, cols / 4, rows, n);

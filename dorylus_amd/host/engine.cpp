@@ -264,6 +264,10 @@ int dory_engine_run(dory_engine *e, uint32_t epochs, double *epoch_ms) {
     int64_t want_graph = 0;
     if (dory_get_option(e->eng->ctx, "epoch_graph", &want_graph)) want_graph = 0;
     if (e->numNodes > 1) want_graph = 0;   // the exchange is not recorded
+    if (e->recorded) {   // dory_preallocate / dory_graph_upload drop a recorded epoch behind the engine's back
+        int64_t have = 0;
+        if (dory_get_option(e->eng->ctx, "epoch_graph_recorded", &have) || !have) e->recorded = false;
+    }
     if (!want_graph && e->recorded) {
         dory_epoch_graph_drop(e->eng->ctx);
         e->recorded = false;

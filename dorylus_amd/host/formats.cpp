@@ -65,6 +65,8 @@ int dory_read_features(const char *path, const dory_partition *p, uint32_t expec
         if (FILE *c = fopen(cache.c_str(), "rb")) {
             const size_t nl = (size_t)v.local_vtx_cnt * F, ng = (size_t)v.src_ghost_cnt * F;
             bool ok = (nl == 0 || fread(local, 4, nl, c) == nl) && (ng == 0 || (ghost && fread(ghost, 4, ng, c) == ng));
+            char extra;
+            ok = ok && fread(&extra, 1, 1, c) == 0;   // a cache of another partitioning with more rows is not this one's
             fclose(c);
             if (ok) return DORY_OK;
         }
@@ -91,6 +93,10 @@ int dory_read_features(const char *path, const dory_partition *p, uint32_t expec
     }
     fclose(f);
     if (gvid != v.global_vtx_cnt) return ferr(DORY_ERR_IO, "features file row count != globalVtxCnt");
+    // the single forward scan relies on both id lists ascending (graph.cpp:34-60 writes them so): rows left
+    // unfilled mean a partition file whose ghost / local ids are in another order -- refuse, do not cache zeros
+    if (gi != v.src_ghost_cnt || li != v.local_vtx_cnt)
+        return ferr(DORY_ERR_IO, "features: local or ghost global ids of the partition do not ascend (rows left unfilled)");
     if (!cache.empty()) {
         if (FILE *c = fopen(cache.c_str(), "wb")) {
             fwrite(local, 4, (size_t)v.local_vtx_cnt * F, c);

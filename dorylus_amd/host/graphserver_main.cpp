@@ -182,10 +182,15 @@ int main(int argc, char **argv) {
     CK(dory_weights_init_xavier(ctx));
     CK(dory_adam_config(ctx, lr));
     if (numNodes > 1) {  // RCCL bootstrap over a file in tmpdir (single node, shared filesystem)
-        const std::string idFile = tmpDir + "/dorylus_rccl_id.bin";
+        // one id file per job: the launcher's rendezvous port (or DORY_JOB_ID) is the nonce, so a file left by a
+        // crashed run or written by a concurrent job is never mistaken for this job's id
+        const char *nonce = getenv("DORY_JOB_ID");
+        if (!nonce || !*nonce) nonce = getenv("MASTER_PORT");
+        const std::string idFile = tmpDir + "/dorylus_rccl_id." + (nonce && *nonce ? nonce : "default") + ".bin";
         unsigned char id[128];
         if (nodeId == 0) {
             if (dory_comm_unique_id(id)) DIE("ncclGetUniqueId failed");
+            remove(idFile.c_str());   // stale file of an earlier job with the same nonce
             const std::string tmp = idFile + ".tmp";
             FILE *f = fopen(tmp.c_str(), "wb");
             if (!f || fwrite(id, 1, 128, f) != 128) DIE("cannot write %s", tmp.c_str());
