@@ -24,7 +24,13 @@ SYMBOLS = [
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
     "dory_gatmh_heads", "dory_transform_first_active", "dory_transform_first_layer",
+    "dory_comm_set_host_transport",
 ]
+
+# host transport callbacks (include/dorylus_hip.h)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                           C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_uint64)
 
 FORWARD, BACKWARD = 0, 1
 GCN, GAT, GATMH = 0, 1, 2
@@ -85,6 +91,7 @@ def load():
         "dory_epoch_graph_drop": [vp],
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
         "dory_gatmh_heads": [vp, vp],
+        "dory_comm_set_host_transport": [vp, ALLTOALLV_FN, ALLREDUCE_FN, vp],
         # include/dorylus_host.h
         "dory_partition_build": [vp, vp, u64, vp, u32, u32, u32, i32, C.POINTER(vp)],
         "dory_partition_build_from_files": [cp, u32, u32, i32, C.POINTER(vp)],
@@ -277,6 +284,40 @@ class Context:
     def comm_init(self, id128, rank, nranks):
         b = np.ascontiguousarray(id128, np.uint8)
         self._ck(self.lib.dory_comm_init(self.h, _ptr(b), rank, nranks))
+
+    def set_host_transport(self, alltoallv, allreduce):
+        """alltoallv(send: np.ndarray, send_counts, send_offsets, recv: np.ndarray, recv_counts, recv_offsets) and
+        allreduce(buf: np.ndarray) move host floats between the ranks (e.g. over gloo); everything else of the
+        multi-rank epoch stays in the library.  (None, None) returns to RCCL."""
+        if alltoallv is None:
+            self._tx = None
+            self._ck(self.lib.dory_comm_set_host_transport(self.h, ALLTOALLV_FN(0), ALLREDUCE_FN(0), None))
+            return
+
+        def a2a(user, send, sc, so, recv, rc, ro, P):
+            try:
+                scn, son = np.ctypeslib.as_array(sc, (P,)).copy(), np.ctypeslib.as_array(so, (P,)).copy()
+                rcn, ron = np.ctypeslib.as_array(rc, (P,)).copy(), np.ctypeslib.as_array(ro, (P,)).copy()
+                ns, nr = int((son + scn).max()), int((ron + rcn).max())
+                sa = np.ctypeslib.as_array(send, (max(ns, 1),))
+                ra = np.ctypeslib.as_array(recv, (max(nr, 1),))
+                alltoallv(sa, scn, son, ra, rcn, ron)
+                return 0
+            except Exception:       # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def ar(user, buf, n):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, (int(n),)))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._tx = (ALLTOALLV_FN(a2a), ALLREDUCE_FN(ar))      # keep the thunks alive
+        self._ck(self.lib.dory_comm_set_host_transport(self.h, self._tx[0], self._tx[1], None))
 
     def halo_exchange(self, layer, direction):
         self._ck(self.lib.dory_halo_exchange(self.h, layer, direction))

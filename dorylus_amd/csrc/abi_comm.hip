@@ -41,6 +41,36 @@ int dory_halo_plan(dory_ctx *c, int dir, const uint32_t *send_counts, const uint
     if ((rc = upload_array(c, &p.d_send_lvids, send_lvids, p.send_total))) return rc;
     if ((rc = upload_array(c, &p.d_recv_slots, recv_slots, p.recv_total))) return rc;
     p.set = true;
+    // pack / receive buffers for the widest row any layer exchanges, now, so that no allocation (and no device-wide
+    // synchronisation) happens inside an epoch
+    uint32_t w = 0;
+    for (uint32_t l = 0; l <= c->L; ++l) {
+        w = std::max(w, pad_ld(c->dims[l]));
+        if (c->gnn == DORY_GATMH && l < c->L && l < c->heads.size()) w = std::max(w, pad_ld(c->dims[l + 1] * c->heads[l]));
+    }
+    const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
+    if (sb > c->send_cap || rb > c->recv_cap) HIPCK(c, hipDeviceSynchronize());
+    if (sb > c->send_cap) {
+        if (c->send_buf) (void)hipFree(c->send_buf);
+        c->send_buf = nullptr; c->send_cap = 0;
+        HIPCK(c, hipMalloc((void **)&c->send_buf, sb));
+        c->send_cap = sb;
+    }
+    if (rb > c->recv_cap) {
+        if (c->recv_buf) (void)hipFree(c->recv_buf);
+        c->recv_buf = nullptr; c->recv_cap = 0;
+        HIPCK(c, hipMalloc((void **)&c->recv_buf, rb));
+        c->recv_cap = rb;
+    }
+    return DORY_OK;
+}
+
+int dory_comm_set_host_transport(dory_ctx *c, dory_alltoallv_fn alltoallv, dory_allreduce_fn allreduce_sum, void *user) {
+    CHECK_CTX(c);
+    if ((alltoallv == nullptr) != (allreduce_sum == nullptr)) return fail(c, DORY_ERR_ARG, "set_host_transport: both callbacks or none");
+    c->tx_a2a = alltoallv;
+    c->tx_ar = allreduce_sum;
+    c->tx_user = user;
     return DORY_OK;
 }
 
@@ -123,22 +153,27 @@ namespace dory {
 int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) {
     HaloPlan &p = c->plan[dir];
     if (!p.set) return fail(c, DORY_ERR_ARG, "halo_exchange: no plan");
-    if (!c->nccl) return fail(c, DORY_ERR_COMM, "halo_exchange: dory_comm_init not called");
-    if (c->nranks != (int)c->numNodes) return fail(c, DORY_ERR_COMM, "halo_exchange: communicator size != num_nodes");
+    if (!c->tx_a2a) {
+        if (!c->nccl) return fail(c, DORY_ERR_COMM, "halo_exchange: dory_comm_init not called");
+        if (c->nranks != (int)c->numNodes) return fail(c, DORY_ERR_COMM, "halo_exchange: communicator size != num_nodes");
+    }
     if (src->ld != ghost->ld) return fail(c, DORY_ERR_ARG, "halo_exchange: row widths of source and ghost tensor differ");
     const uint32_t w = src->ld;  // padded row width travels (keeps 16-B lanes)
     const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
-    if (sb > c->send_cap) {
-        HIPCK(c, hipDeviceSynchronize());
-        if (c->send_buf) (void)hipFree(c->send_buf);
-        HIPCK(c, hipMalloc((void **)&c->send_buf, sb));
-        c->send_cap = sb;
-    }
-    if (rb > c->recv_cap) {
-        HIPCK(c, hipDeviceSynchronize());
-        if (c->recv_buf) (void)hipFree(c->recv_buf);
-        HIPCK(c, hipMalloc((void **)&c->recv_buf, rb));
-        c->recv_cap = rb;
+    if (sb > c->send_cap || rb > c->recv_cap) {   // not reached after dory_halo_plan sized them for the widest layer (a
+        HIPCK(c, hipDeviceSynchronize());          // tensor uploaded with other dimensions than dory_configure's)
+        if (sb > c->send_cap) {
+            if (c->send_buf) (void)hipFree(c->send_buf);
+            c->send_buf = nullptr; c->send_cap = 0;
+            HIPCK(c, hipMalloc((void **)&c->send_buf, sb));
+            c->send_cap = sb;
+        }
+        if (rb > c->recv_cap) {
+            if (c->recv_buf) (void)hipFree(c->recv_buf);
+            c->recv_buf = nullptr; c->recv_cap = 0;
+            HIPCK(c, hipMalloc((void **)&c->recv_buf, rb));
+            c->recv_cap = rb;
+        }
     }
     // comm stream waits for the producer of `src` on the compute stream
     HIPCK(c, hipEventRecord(c->ev_a, c->compute));
@@ -146,6 +181,22 @@ int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) 
     {
         Timed t(c, "halo", c->comm);
         HIPCK(c, launch_gather_rows(c->send_buf, src->d, src->ld, w, p.d_send_lvids, p.send_total, c->comm));
+        if (c->tx_a2a) {   // host transport: same pack / unpack / events, the bytes travel through the caller
+            c->tx_send.resize((size_t)p.send_total * w);
+            c->tx_recv.resize((size_t)p.recv_total * w);
+            if (sb) HIPCK(c, hipMemcpyAsync(c->tx_send.data(), c->send_buf, sb, hipMemcpyDeviceToHost, c->comm));
+            HIPCK(c, hipStreamSynchronize(c->comm));
+            std::vector<uint64_t> sc(c->numNodes), so(c->numNodes), rc_(c->numNodes), ro(c->numNodes);
+            for (uint32_t peer = 0; peer < c->numNodes; ++peer) {
+                sc[peer] = (uint64_t)p.send_counts[peer] * w; so[peer] = (uint64_t)p.send_off[peer] * w;
+                rc_[peer] = (uint64_t)p.recv_counts[peer] * w; ro[peer] = (uint64_t)p.recv_off[peer] * w;
+            }
+            if (c->tx_a2a(c->tx_user, c->tx_send.data(), sc.data(), so.data(), c->tx_recv.data(), rc_.data(), ro.data(), c->numNodes))
+                return fail(c, DORY_ERR_COMM, "halo_exchange: host transport alltoallv failed");
+            if (rb) HIPCK(c, hipMemcpyAsync(c->recv_buf, c->tx_recv.data(), rb, hipMemcpyHostToDevice, c->comm));
+            HIPCK(c, launch_scatter_rows(ghost->d, c->recv_buf, ghost->ld, w, p.d_recv_slots, p.recv_total, c->comm));
+            HIPCK(c, hipStreamSynchronize(c->comm));   // tx_recv is reused by the next exchange
+        } else {
         ncclComm_t comm = (ncclComm_t)c->nccl;
         NCCLCK(c, ncclGroupStart());
         for (uint32_t peer = 0; peer < c->numNodes; ++peer) {
@@ -159,6 +210,7 @@ int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) 
         }
         NCCLCK(c, ncclGroupEnd());
         HIPCK(c, launch_scatter_rows(ghost->d, c->recv_buf, ghost->ld, w, p.d_recv_slots, p.recv_total, c->comm));
+        }
     }
     HIPCK(c, hipEventRecord(c->ev_b, c->comm));
     if (defer && c->opt["halo_overlap"]) c->halo_pending = true;
@@ -234,7 +286,15 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
         Tensor &w = kv.second;
         Tensor &g = c->wgrads[layer][name];
         const uint64_t n = (uint64_t)w.rows * w.ld;
-        if (c->numNodes > 1) {
+        if (c->numNodes > 1 && c->tx_ar) {   // host transport
+            Timed t(c, "allreduce", c->compute);
+            c->tx_send.resize(n);
+            HIPCK(c, hipMemcpyAsync(c->tx_send.data(), g.d, n * sizeof(float), hipMemcpyDeviceToHost, c->compute));
+            HIPCK(c, hipStreamSynchronize(c->compute));
+            if (c->tx_ar(c->tx_user, c->tx_send.data(), n)) return fail(c, DORY_ERR_COMM, "weight_update: host transport allreduce failed");
+            HIPCK(c, hipMemcpyAsync(g.d, c->tx_send.data(), n * sizeof(float), hipMemcpyHostToDevice, c->compute));
+            HIPCK(c, hipStreamSynchronize(c->compute));
+        } else if (c->numNodes > 1) {
             if (!c->nccl) return fail(c, DORY_ERR_COMM, "weight_update: dory_comm_init not called");
             // sum of per-partition updates (WeightTensor::localUpdate/ghostUpdate,
             // src/weight-server/weighttensor.cpp:131-166) as one RCCL all-reduce

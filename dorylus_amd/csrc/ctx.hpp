@@ -139,6 +139,11 @@ struct dory_ctx {
     float *send_buf = nullptr, *recv_buf = nullptr;
     size_t send_cap = 0, recv_cap = 0;
     void *nccl = nullptr;  // ncclComm_t
+    // host transport (dory_comm_set_host_transport): callbacks + host staging
+    dory_alltoallv_fn tx_a2a = nullptr;
+    dory_allreduce_fn tx_ar = nullptr;
+    void *tx_user = nullptr;
+    std::vector<float> tx_send, tx_recv;
     int rank = 0, nranks = 1;
 
     // epoch graph (hipGraph replay of one captured epoch; single partition)

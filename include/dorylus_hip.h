@@ -162,6 +162,17 @@ int dory_halo_plan(dory_ctx *ctx, int dir, const uint32_t *send_counts,
  * the same bytes.  With num_nodes == 1 none of this is needed. */
 int dory_comm_unique_id(void *id128);
 int dory_comm_init(dory_ctx *ctx, const void *id128, int rank, int nranks);
+/* Host transport instead of RCCL: the exchange step and the gradient sum call back into the host program with
+ * host buffers -- the seam where the reference's own CommManager / ZeroMQ data path (gcn_ops.cpp:204-362:
+ * verticesPushOut + ghostReceiver*, weighttensor.cpp:131-166 for the update sum) or any MPI can carry the bytes.
+ * Everything else of the multi-rank path (plan, pack, unpack, stream ordering, overlap with the local-source
+ * aggregation, Adam) stays the library's.  alltoallv: floats, per-peer counts and offsets (num_nodes entries
+ * each, self entry 0); allreduce: in-place sum over all ranks.  Callbacks return 0 on success and run on the
+ * calling thread, between two stream synchronisations.  Passing NULLs returns to RCCL. */
+typedef int (*dory_alltoallv_fn)(void *user, const float *send, const uint64_t *send_counts, const uint64_t *send_offsets,
+                                 float *recv, const uint64_t *recv_counts, const uint64_t *recv_offsets, uint32_t num_nodes);
+typedef int (*dory_allreduce_fn)(void *user, float *buf, uint64_t n);
+int dory_comm_set_host_transport(dory_ctx *ctx, dory_alltoallv_fn alltoallv, dory_allreduce_fn allreduce_sum, void *user);
 /* pack -> grouped ncclSend/ncclRecv (all-to-all-v) -> unpack into fg / bg
  * (GCN: fwd sends h@(layer-1) into fg@layer, bwd sends grad@layer into bg@(layer-1);
  *  GAT: fwd z@(layer-1) -> fg_z@(layer-1), bwd grad@(layer-1) -> bg_d@(layer-1);

@@ -1,0 +1,188 @@
+"""The multi-rank path as far as one GPU allows: two (and three) *processes* share device 0, each is one rank running
+`dory_engine_run` -- partition upload with the C++ halo plans, pack -> exchange -> unpack on the comm stream with the
+event ordering of the overlapped schedule, interior-source SpMM blocks under the exchange, gradient sum, Adam -- and
+only the bytes travel differently: `dory_comm_set_host_transport` hands the packed rows and the weight gradients to
+gloo instead of RCCL (two ranks cannot share one GPU under RCCL).  Every named tensor of every rank is compared with
+the oracle's epoch over the same partitions (reference semantics: gcn_ops.cpp:204-362 for the exchange,
+weighttensor.cpp:131-166 + AdamOptimizer.cpp:29-51 for the update)."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import torch.distributed as dist
+        import dorylus_amd as da
+        import orc
+        from helpers import oracle_gcn_epoch, rel_err
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dims, V, E, epochs, opts = case["dims"], case["V"], case["E"], case["epochs"], case.get("opts", {})
+        rng = np.random.default_rng(case["seed"])
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        src, dst = np.concatenate([s, d]), np.concatenate([d, s])
+        if case["parts"] == "block":
+            parts = (np.arange(V, dtype=np.int64) * world // V).astype(np.int32)
+        else:
+            parts = rng.integers(0, world, V).astype(np.int32)
+        X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+        labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+        L = len(dims) - 1
+        Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(L)]
+        all_parts = [da.Partition.build(src, dst, parts, r, world) for r in range(world)]   # every rank: oracle side
+        gs = [p.view() for p in all_parts]
+        part, g = all_parts[rank], gs[rank]
+
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, dims, V, rank, world)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        part.upload(ctx, parts)                    # adjacency + both halo plans (dory_partition_upload)
+        ctx.preallocate()
+        ctx.upload(0, "x", X[g["localToGlobal"]])
+        if g["srcGhostCnt"]:
+            ctx.upload(0, "fg", X[g["srcGhost"]].reshape(g["srcGhostCnt"], dims[0]))
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l, W in enumerate(Ws):
+            ctx.weight_set(l, "w", W)
+        ctx.adam_config(0.01)
+
+        calls = {"a2a": 0, "ar": 0, "bytes": 0}
+
+        def alltoallv(send, sc, so, recv, rc, ro):
+            calls["a2a"] += 1
+            reqs, keep = [], []
+            for p in range(world):
+                if p == rank:
+                    assert sc[p] == 0 and rc[p] == 0
+                    continue
+                if rc[p]:
+                    t = torch.empty(int(rc[p]), dtype=torch.float32)
+                    keep.append((t, int(ro[p]), int(rc[p])))
+                    reqs.append(dist.irecv(t, p))
+                if sc[p]:
+                    t = torch.from_numpy(send[int(so[p]):int(so[p] + sc[p])].copy())
+                    calls["bytes"] += 4 * int(sc[p])
+                    reqs.append(dist.isend(t, p))
+            for r_ in reqs:
+                r_.wait()
+            for t, o, n in keep:
+                recv[o:o + n] = t.numpy()
+
+        def allreduce(buf):
+            calls["ar"] += 1
+            t = torch.from_numpy(buf.copy())
+            dist.all_reduce(t)
+            buf[:] = t.numpy()
+        ctx.set_host_transport(alltoallv, allreduce)
+
+        eng = da.NativeEngine(ctx)
+        eng.run(epochs)
+        ctx.sync()
+
+        # ---- oracle: the same epochs over the same partitions, Adam on the summed gradients ----
+        Wo = [w.copy() for w in Ws]
+        m = [np.zeros_like(w) for w in Ws]
+        v = [np.zeros_like(w) for w in Ws]
+        T = dW = None
+        for ep in range(epochs):
+            T, dW = oracle_gcn_epoch(gs, parts, X, labels, Wo, V)
+            for l in range(L - 1, -1, -1):
+                orc.adam_update(Wo[l], dW[l], m[l], v[l], 0.01, ep + 1)
+        errs = {}
+        if g["localVtxCnt"]:
+            for l in range(L):
+                errs[f"ah{l}"] = rel_err(ctx.download(l, "ah"), T[rank][f"ah{l}"])
+                if l < L - 1:
+                    errs[f"h{l}"] = rel_err(ctx.download(l, "h"), T[rank][f"h{l}"])
+                    errs[f"aTg{l}"] = rel_err(ctx.download(l, "aTg"), T[rank][f"aTg{l}"])
+                if l > 0:
+                    errs[f"grad{l}"] = rel_err(ctx.download(l, "grad"), T[rank][f"grad{l}"])
+                    if g["srcGhostCnt"]:
+                        # ghost rows are the owners' rows bit for bit (they were computed on the other process)
+                        errs[f"fg{l}"] = rel_err(ctx.download(l, "fg"), T[rank][f"fg{l}"])
+                    if g["dstGhostCnt"]:
+                        errs[f"bg{l-1}"] = rel_err(ctx.download(l - 1, "bg"), T[rank][f"bg{l-1}"])
+        for l in range(L):
+            errs[f"dW{l}"] = rel_err(ctx.weight_grad_get(l), dW[l])        # the all-reduced sum, on every rank
+            errs[f"W{l}"] = rel_err(ctx.weight_get(l), Wo[l])             # after `epochs` identical Adam steps
+        # the exchanged ghost rows themselves: identical bits on owner and receiver
+        own_h = ctx.download(0, "h")
+        allh = [None] * world
+        dist.all_gather_object(allh, (g["localToGlobal"], own_h))
+        if g["srcGhostCnt"]:
+            g2row = {}
+            for l2g, hh in allh:
+                for i, gv in enumerate(l2g):
+                    g2row[int(gv)] = hh[i]
+            want = np.stack([g2row[int(gv)] for gv in g["srcGhost"]])
+            errs["fg1_bits"] = 0.0 if np.array_equal(ctx.download(1, "fg"), want) else 1.0
+        expect_a2a = epochs * 2 * (L - 1)
+        ok_calls = calls["a2a"] == expect_a2a and calls["ar"] == epochs * L
+        eng.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, errs, ok_calls, calls))
+    except Exception:
+        q.put((rank, traceback.format_exc(), False, None))
+
+
+CASES = {
+    "two_ranks_reddit_dims": dict(dims=[602, 128, 41], V=3000, E=40000, seed=1, epochs=2, parts="block"),
+    "two_ranks_hash_parts_3layer": dict(dims=[300, 64, 64, 25], V=2500, E=30000, seed=2, epochs=2, parts="hash"),
+    "three_ranks_sweep_blocks": dict(dims=[128, 128, 16], V=30000, E=300000, seed=3, epochs=1, parts="block",
+                                     opts={"spmm_blk_nb": 16}),   # K1s in two launches: local-source blocks under the exchange
+    "two_ranks_no_overlap": dict(dims=[64, 32, 8], V=2000, E=20000, seed=4, epochs=1, parts="hash", opts={"halo_overlap": 0}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_engine_epochs_two_processes_one_gpu(name):
+    import torch.multiprocessing as mp
+    case = CASES[name]
+    world = 3 if name.startswith("three") else 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, errs, ok_calls, calls in sorted(res, key=lambda t: t[0]):
+        assert isinstance(errs, dict), f"rank {rank} failed:\n{errs}"
+        assert ok_calls, (rank, calls)
+        bad = {k: e for k, e in errs.items() if not e < RTOL}
+        assert not bad, (rank, bad)
