@@ -17,7 +17,7 @@ SYMBOLS = [
     "dory_create", "dory_destroy", "dory_last_error", "dory_set_streams", "dory_sync",
     "dory_configure", "dory_graph_upload", "dory_preallocate", "dory_tensor_info",
     "dory_tensor_upload", "dory_tensor_download", "dory_tensor_fill_uniform", "dory_labels_upload",
-    "dory_weight_set", "dory_weight_get", "dory_weight_grad_get", "dory_weights_init_xavier",
+    "dory_weight_set", "dory_weight_get", "dory_weight_grad_get", "dory_weight_grad_set", "dory_weights_init_xavier",
     "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
     "dory_halo_unpack", "dory_halo_pack_tensor", "dory_halo_unpack_tensor", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
@@ -64,6 +64,7 @@ def load():
         "dory_weight_set": [vp, u32, cp, vp],
         "dory_weight_get": [vp, u32, cp, vp],
         "dory_weight_grad_get": [vp, u32, cp, vp],
+        "dory_weight_grad_set": [vp, u32, cp, vp],
         "dory_weights_init_xavier": [vp],
         "dory_aggregate": [vp, u32, i32],
         "dory_apply_vertex": [vp, u32, i32],
@@ -244,6 +245,11 @@ class Context:
         w = np.empty(self._wshape(layer, name), np.float32)
         self._ck(self.lib.dory_weight_grad_get(self.h, layer, name.encode(), _ptr(w)))
         return w
+
+    def weight_grad_set(self, layer, grad, name="w"):
+        g = np.ascontiguousarray(grad, np.float32)
+        assert g.shape == self._wshape(layer, name)
+        self._ck(self.lib.dory_weight_grad_set(self.h, layer, name.encode(), _ptr(g)))
 
     def weights_init_xavier(self):
         self._ck(self.lib.dory_weights_init_xavier(self.h))

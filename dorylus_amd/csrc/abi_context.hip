@@ -628,6 +628,13 @@ int dory_weight_grad_get(dory_ctx *c, uint32_t layer, const char *name, float *h
     return download_dense(c, *t, host);
 }
 
+int dory_weight_grad_set(dory_ctx *c, uint32_t layer, const char *name, const float *host) {
+    CHECK_CTX(c);
+    Tensor *t = name ? findw(c->wgrads, layer, name) : nullptr;
+    if (!t || !host) return fail(c, DORY_ERR_ARG, "weight_grad_set: no gradient '%s' at layer %u", name ? name : "(null)", layer);
+    return upload_dense(c, *t, host);
+}
+
 int dory_weights_init_xavier(dory_ctx *c) {
     CHECK_CTX(c);
     if (!c->prealloc) return fail(c, DORY_ERR_ARG, "weights_init: preallocate first");

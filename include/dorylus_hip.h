@@ -127,6 +127,9 @@ int dory_labels_upload(dory_ctx *ctx, const uint32_t *labels);
 int dory_weight_set(dory_ctx *ctx, uint32_t layer, const char *name, const float *host);
 int dory_weight_get(dory_ctx *ctx, uint32_t layer, const char *name, float *host);
 int dory_weight_grad_get(dory_ctx *ctx, uint32_t layer, const char *name, float *host);
+/* the weight server's side of a push (WeightTensor::localUpdate, weighttensor.cpp:131-150): overwrite the
+ * gradient the next dory_weight_update applies -- for callers that sum the updates themselves */
+int dory_weight_grad_set(dory_ctx *ctx, uint32_t layer, const char *name, const float *host);
 /* WeightServer::xavierInitializer, seed 8888 (src/weight-server/weightserver.cpp:567-585) */
 int dory_weights_init_xavier(dory_ctx *ctx);
 

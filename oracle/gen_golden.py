@@ -35,7 +35,10 @@ def toy_edges(seed, V, E, hub=False, symmetric=False, dedup=False):
     rng = np.random.default_rng(seed)
     src = rng.integers(0, V, E)
     dst = rng.integers(0, V, E)
-    if hub:  # one high in-degree vertex + one high out-degree vertex
+    if hub == "big":  # > 8192 edges on one destination and on one source
+        dst[:11000] = 7
+        src[11000:21000] = 2900
+    elif hub:  # one high in-degree vertex + one high out-degree vertex
         k = E // 4
         dst[:k] = 3 % V
         src[k:2 * k] = 5 % V
@@ -57,6 +60,9 @@ def gen_partition_fixtures():
         ("toy60_p4_hash", 60, 500, 4, 0, True, "hash"),
         ("toy97_p8_und", 97, 700, 8, 1, False, "rand"),
         ("toy40_p3_empty", 40, 200, 3, 0, False, "skip1"),  # partition 1 owns nothing
+        # one destination with > 8192 in-edges and one source with > 8192 out-edges (K1's long-row clamp and the
+        # blocked kernels' hub segments run on bytes the reference's DataLoader wrote), two partitions with ghosts
+        ("hub3000_p2", 3000, 52000, 2, 0, "big", "block"),
     ]
     exe = os.path.join(HERE, "_ref", "ref_preprocess")
     for name, V, E, P, und, hub, kind in cases:
@@ -138,7 +144,64 @@ def gen_numpy_gnn_fixture():
     print("numpy-gnn fixture written")
 
 
+def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
+    """The reference's numpy GCN at ~2 000 vertices with the layer widths of a BASELINE config (any depth).  Kept small:
+    inputs are regenerated from the stored seed-free arrays (edges, X, labels, W), expected outputs are float32 rows of
+    a fixed sample of vertices for every intermediate tensor plus the complete weight gradients."""
+    sys.path.insert(0, os.path.join(REF, "miscs", "numpy-gnn"))
+    import layers as ref_layers
+    import load_data as ref_load
+    import loss as ref_loss
+    L = len(dims) - 1
+    src, dst = toy_edges(seed, V, E, symmetric=True, dedup=True)
+    rng = np.random.default_rng(seed + 1)
+    Xq = rng.integers(-64, 65, (V, dims[0])).astype(np.int8)      # features in 1/64 steps: one byte each in the fixture
+    X = Xq.astype(np.float32) / np.float32(64)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(L)]
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        po.write_bsnap_edges(d + "graph.bsnap", V, src, dst)
+        po.write_features(d + "features.bsnap", X)
+        po.write_labels(d + "labels.bsnap", labels, dims[-1])
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            A_hat, feats, tl = ref_load.load_data(d, "toy", binary=True)
+    onehot = np.eye(dims[-1])[tl]
+    aggs = [ref_layers.Aggregate(f"A{l}", A_hat) for l in range(L)]
+    lins = [ref_layers.Linear(f"W{l}", dims[l], dims[l + 1], "xavier").set_W(Ws[l].astype(np.float64)) for l in range(L)]
+    acts = [ref_layers.Tanh(f"T{l}") for l in range(L - 1)]
+    lossf = ref_loss.SoftmaxCrossEntropyLoss("loss")
+    out = {}
+    h = feats.astype(np.float64)
+    for l in range(L):
+        out[f"ah{l}"] = aggs[l].forward(h)
+        out[f"z{l}"] = lins[l].forward(out[f"ah{l}"])
+        if l < L - 1:
+            h = out[f"h{l}"] = acts[l].forward(out[f"z{l}"])
+    out["d"] = lossf.backward(out[f"z{L-1}"], onehot)
+    grad = lins[L - 1].backward(out["d"])
+    out[f"dW{L-1}"] = lins[L - 1].grad_W
+    for l in range(L - 1, 0, -1):
+        out[f"grad{l}"] = grad
+        out[f"aTg{l-1}"] = aggs[l].backward(grad)
+        out[f"g{l-1}"] = acts[l - 1].backward(out[f"aTg{l-1}"])
+        grad = lins[l - 1].backward(out[f"g{l-1}"])
+        out[f"dW{l-1}"] = lins[l - 1].grad_W
+    sample = np.sort(np.random.default_rng(seed + 2).choice(V, rows, replace=False))
+    store = {"V": V, "src": src, "dst": dst, "X_q64": Xq, "labels": labels, "sample": sample, "dims": np.asarray(dims)}
+    for l in range(L):
+        store[f"W{l}"] = Ws[l]
+    for k, v in out.items():
+        store[k] = v.astype(np.float32) if k.startswith("dW") else v[sample].astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **store)
+    print("numpy-gnn fixture", name, "written:", os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     gen_partition_fixtures()
     gen_numpy_gnn_fixture()
+    gen_numpy_gnn_large("numpy_gnn_reddit_dims", [602, 128, 41])            # BASELINE config 2 widths
+    gen_numpy_gnn_large("numpy_gnn_amazon_dims", [300, 64, 64, 25], seed=29)  # config 4: 3 layers

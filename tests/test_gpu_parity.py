@@ -186,6 +186,39 @@ def test_sweep_variant_several_sweeps_and_unit_weights(da):
         assert rel_err(res[2][k], res[0][k]) < (1e-4 if k[0] in ("z", "ah") else 2e-3), k
 
 
+@pytest.mark.parametrize("F", [41, 602])
+def test_hub_partition_built_by_the_reference(da, F):
+    """tests/golden/parts_hub3000_p2: graph.<id>.bin bytes written by the reference's own DataLoader, with one
+    destination of 11 000 in-edges and one source of 10 000 out-edges (beyond K1's 8 192-edge row clamp and the blocked
+    kernels' 2 048-edge segment clamp), two partitions with ghosts: K1 + long-row kernels, K1b + long-segment kernels,
+    and the default variant (which hands hub graphs to K1b) against the oracle, forward and backward."""
+    import orc
+    from helpers import make_ctx, rel_err
+    gs, parts = _golden_partitions("parts_hub3000_p2")
+    assert max(np.diff(g["colPtr"].astype(np.int64)).max() for g in gs) > 8192
+    assert max(np.diff(g["rowPtr"].astype(np.int64)).max() for g in gs) > 8192
+    rng = np.random.default_rng(F)
+    for r, g in enumerate(gs):
+        N = g["localVtxCnt"]
+        ctx = make_ctx(da, g, [F, F, 3], g["globalVtxCnt"], node_id=r, num_nodes=len(gs))
+        x = rng.standard_normal((N, F)).astype(np.float32)
+        fg = rng.standard_normal((g["srcGhostCnt"], F)).astype(np.float32)
+        gr = rng.standard_normal((N, F)).astype(np.float32)
+        bg = rng.standard_normal((g["dstGhostCnt"], F)).astype(np.float32)
+        ctx.upload(0, "x", x); ctx.upload(0, "fg", fg); ctx.upload(1, "grad", gr); ctx.upload(0, "bg", bg)
+        ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x, fg)
+        ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr, bg)
+        for variant, nb in ((0, 0), (1, 8), (2, 8), (2, 16)):
+            ctx.set_option("spmm_variant", variant)
+            ctx.set_option("spmm_blk_nb", nb)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            # 10 000-term sums in chunk / block order instead of edge order: the path's 1e-4 bar
+            assert rel_err(ctx.download(0, "ah"), ref_f) < RTOL, (r, F, variant, nb)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < RTOL, (r, F, variant, nb)
+        ctx.close()
+
+
 def test_blocked_variant_many_blocks(da):
     """enough source rows for several rounds of 8 blocks (nb = 16+), skewed degrees."""
     import orc
@@ -551,6 +584,40 @@ def test_gcn_numpy_gnn_fixture(da, golden_dir):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims"])
+def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
+    """The reference's Python GCN at the widths of BASELINE configs 2 and 4 (602-128-41 / 300-64-64-25, 1 500 vertices):
+    the forward half of the epoch through the C-ABI on the fixture's sampled rows."""
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    V = int(z["V"])
+    dims = [int(x) for x in z["dims"]]
+    L = len(dims) - 1
+    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    rows = z["sample"]
+    for variant, nb in ((2, 8), (0, 0)):          # the sweep kernel (forced on this L2-sized graph) and the row gather
+        ctx = make_ctx(da, g, dims, V)
+        ctx.set_option("spmm_variant", variant)
+        ctx.set_option("spmm_blk_nb", nb)
+        ctx.upload(0, "x", z["X_q64"].astype(np.float32) / np.float32(64))
+        for l in range(L):
+            ctx.weight_set(l, "w", z[f"W{l}"])
+        ctx.labels_upload(z["labels"])
+        for l in range(L):
+            ctx.aggregate(l, da.FORWARD)
+            ctx.apply_vertex(l, da.FORWARD)
+        # forward tensors only: the reference's C++ last layer differs from its Python model behind z_L (maskout of the
+        # non-training rows and the 1/(V*0.66) scale, CPU_comm.cpp:126-146) -- the backward half at these widths is
+        # checked against the C oracle by test_gcn_epoch_vs_oracle, and the oracle against this fixture on the CPU
+        for l in range(L):
+            assert rel_err(ctx.download(l, "ah")[rows], z[f"ah{l}"]) < RTOL, (name, variant, l)
+            assert rel_err(ctx.download(l, "z")[rows], z[f"z{l}"]) < RTOL, (name, variant, l)
+            if l < L - 1:
+                assert rel_err(ctx.download(l, "h")[rows], z[f"h{l}"]) < RTOL
+        ctx.close()
+
+
 def test_adam_and_xavier_vs_oracle(da):
     import orc
     import partition_oracle as po
@@ -580,6 +647,27 @@ def test_adam_and_xavier_vs_oracle(da):
             orc.adam_update(W[l], grads[l], m[l], v[l], 0.01, ep)
         for l in (0, 1):
             assert rel_err(ctx.weight_get(l), W[l]) < 1e-6, (ep, l)
+    ctx.close()
+
+
+def test_adam_reference_known_answer(da):
+    """K7 on the one output of the reference's real AdamOptimizer on record (AdamOptimizer.cpp linked into
+    a harness, w = 0.5, g = 0.1, lr = 0.01, first iteration -> 0.49000031): every weight, both layers, bit for bit."""
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph
+    V, dims = 64, [10, 6, 4]
+    s, d = random_graph(3, V, 300)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    ctx = make_ctx(da, g, dims, V)
+    ctx.adam_config(0.01)
+    for l in (0, 1):
+        ctx.weight_set(l, "w", np.full((dims[l], dims[l + 1]), 0.5, np.float32))
+        ctx.weight_grad_set(l, np.full((dims[l], dims[l + 1]), 0.1, np.float32))
+    ctx.weight_update(1)
+    ctx.weight_update(0)
+    for l in (0, 1):
+        w = ctx.weight_get(l)
+        assert np.all(w == np.float32(0.49000031)), (l, w.ravel()[:3])
     ctx.close()
 
 

@@ -69,6 +69,54 @@ def test_gcn_epoch_matches_numpy_gnn(fx):
     assert rel_err(dW0, z["dW0"]) < RTOL
 
 
+def _oracle_epoch_any_depth(z, g):
+    """the C oracle's epoch for the large numpy-gnn fixtures (any depth), full tensors"""
+    dims = [int(x) for x in z["dims"]]
+    L = len(dims) - 1
+    X = z["X_q64"].astype(np.float32) / np.float32(64)
+    Ws = [z[f"W{l}"] for l in range(L)]
+    out = {}
+    h = X
+    for l in range(L):
+        out[f"ah{l}"] = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], h)
+        if l < L - 1:
+            out[f"z{l}"], out[f"h{l}"] = orc.vtx_forward_hidden(out[f"ah{l}"], Ws[l])
+            h = out[f"h{l}"]
+        else:
+            out[f"z{l}"] = orc.sgemm(out[f"ah{l}"], Ws[l])
+    zl = out[f"z{L-1}"]
+    p = np.empty_like(zl)
+    orc.lib.orc_softmax(zl.shape[0], zl.shape[1], zl, p)
+    out["d"] = p - np.eye(dims[-1], dtype=np.float32)[z["labels"]]
+    grad = orc.sgemm(out["d"], Ws[L - 1], tb=True)
+    out[f"dW{L-1}"] = orc.sgemm(out[f"ah{L-1}"], out["d"], ta=True)
+    for l in range(L - 1, 0, -1):
+        out[f"grad{l}"] = grad
+        out[f"aTg{l-1}"] = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], grad)
+        out[f"g{l-1}"], out[f"dW{l-1}"], grad = orc.vtx_backward(out[f"aTg{l-1}"], out[f"z{l-1}"], out[f"ah{l-1}"], Ws[l - 1], l - 1)
+    return out
+
+
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims"])
+def test_gcn_epoch_matches_numpy_gnn_at_baseline_widths(golden_dir, name):
+    """The same pin at the widths of BASELINE configs 2 and 4 (602-128-41; 300-64-64-25, three layers), 1 500 vertices:
+    every intermediate tensor on the fixture's sampled rows and both/all three complete weight gradients against the
+    reference's numpy GCN (fixture made by oracle/gen_golden.py:gen_numpy_gnn_large)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    V = int(z["V"])
+    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    out = _oracle_epoch_any_depth(z, g)
+    rows = z["sample"]
+    checked = 0
+    for k in z.files:
+        if k in out:
+            got = out[k] if k.startswith("dW") else out[k][rows]
+            assert rel_err(got, z[k]) < RTOL, (name, k, rel_err(got, z[k]))
+            checked += 1
+    L = len(z["dims"]) - 1
+    assert checked == 3 * L - 1 + 1 + 3 * (L - 1) + L       # ah,z (L each), h (L-1), d, grad/aTg/g (L-1 each), dW (L)
+
+
 def test_last_layer_sequence_and_quirks():
     """vtxNNForwardGCN last-layer sequence incl. the maskout float-count quirk
     (CPU_comm.cpp:464-471) -- checked against an independent numpy statement."""
@@ -106,6 +154,10 @@ def test_adam_known_answer():
     mm, vv = 0.1 * 0.1, 0.001 * 0.01
     expect = 0.5 - lr_t * mm / (np.sqrt(vv) + 1e-7)
     assert abs(w[0] - expect) < 1e-6
+    # ... and the value the reference's own AdamOptimizer::update printed for this input when the survey linked
+    # src/weight-server/AdamOptimizer.cpp into a harness: 0.49000031 -- the one output of the real
+    # optimizer on record; the float32 nearest to it, exactly
+    assert w[0] == np.float32(0.49000031) and np.all(w == w[0])
 
 
 def test_xavier_stream_properties():
