@@ -155,6 +155,7 @@ int dory_create(int device, dory_ctx **out) {
     (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
+    c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (tried and dropped: warming the next window from waves that wait at a gate, 14.1 -> 15.3 ms)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
     c->opt["spmm_slab"] = 0;

@@ -104,16 +104,17 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             }
             Timed t(c, "spmm", c->compute);
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
+            const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
             if (two) {
-                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, nb_local, done, c->compute));
+                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, nb_local, done, c->compute, sflags));
                 if ((rc = wait_halo(c))) return rc;
                 SpmmArgs a2 = a;
                 a2.self_mode = 0;
                 a2.accumulate = 1;
-                HIPCK(c, launch_spmm_sweep(a2, B, group, row_scale, G, nb_local, B.nb, done, c->compute));
+                HIPCK(c, launch_spmm_sweep(a2, B, group, row_scale, G, nb_local, B.nb, done, c->compute, sflags));
             } else {
                 if ((rc = wait_halo(c))) return rc;
-                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, B.nb, done, c->compute));
+                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, B.nb, done, c->compute, sflags));
             }
             return DORY_OK;
         }

@@ -267,6 +267,7 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
     if (ch <= 16) return launch_t<16, 1>(a, s);
     if (ch <= 32) return launch_t<32, 1>(a, s);
     if (ch <= 64) return launch_t<64, 1>(a, s);
+    if (ch <= 96) return launch_t<32, 3>(a, s);   // e.g. 300 -> 320 floats (Amazon): 80 of 96 lanes-chunks busy instead of 80 of 128
     if (ch <= 128) return launch_t<64, 2>(a, s);
     if (ch <= 192) return launch_t<64, 3>(a, s);
     return launch_t<64, 4>(a, s);           // wider rows: gridDim.y slabs of 1024 floats
@@ -755,6 +756,7 @@ struct SweepArgs {
     uint32_t nsweeps;    // slabs * ceil(tiles_x / G)
     uint32_t b_lo, b_hi; // source blocks of this launch
     uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
+    uint32_t flags;      // reserved for experiments (none active)
 };
 
 template <int GROUP, int R, bool UNIT, bool GH>
@@ -980,7 +982,7 @@ size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nb
 
 // out (+)= self + (row_scale *) sum over source blocks [b_lo, b_hi); `done` = sweep_scratch_bytes() of device memory
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
-                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s) {
+                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, uint32_t flags) {
     if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
     if (!sweep_supported(a, B, group) || b_hi > B.nb || G == 0 || G > 32) return hipErrorInvalidValue;
     const int R = sweep_pick_r(a.N, group, G);
@@ -994,6 +996,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     w.nsweeps = slabs * spp;
     w.b_lo = b_lo; w.b_hi = b_hi;
     w.done = done;
+    w.flags = flags;
     hipError_t e = hipMemsetAsync(done, 0, sweep_scratch_bytes(a, group, G, b_hi - b_lo), s);
     if (e != hipSuccess) return e;
     const dim3 gr(8u * slabs * spp * G), bl(SWEEP_NT);

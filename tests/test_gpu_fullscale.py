@@ -267,3 +267,63 @@ def test_fullscale_gat_prototype_fast_path_vs_general(reddit):
         assert rel_err(res[1][k], res[0][k]) < tol, (k, rel_err(res[1][k], res[0][k]))
         # K1s sums block by block like K1b (with other block boundaries): same bar
         assert rel_err(res[2][k], res[0][k]) < tol, (k, rel_err(res[2][k], res[0][k]))
+
+
+def test_fullscale_amazon_aggregate_properties_and_epoch():
+    """BASELINE config 4 at its real size on one GPU (9 430 088 vertices, ~231.6 M edges, 300-64-64-25): the partition
+    is too large for the blocked kernels (thousands of L2 windows), so this is K1 with 12 GB of source rows, 64-bit
+    offsets into >2^31-byte tensors.  Sampled rows against the oracle (forward F=300 on the CSC, backward F=64 on the
+    CSR), the float64 checksum of checksums, bit-exact scale covariance, and one whole 3-layer epoch with finite values
+    and a validation loss that Adam reduces."""
+    import dorylus_amd as da
+    from bench import WORKLOADS, synth_edges
+    from helpers import rel_err
+    V, E, dims = WORKLOADS["amazon"]
+    src, dst = synth_edges("uniform", V, E)
+    part = da.Partition.build(src, dst, np.zeros(V, np.int32), 0, 1)
+    del src, dst
+    g = part.view()
+    N = int(g["localVtxCnt"])
+    assert N == V and int(g["localInEdgeCnt"]) > 2.2e8
+    ctx = da.Context(0)
+    ctx.configure(da.GCN, dims, V)
+    part.upload(ctx)
+    ctx.preallocate()
+    ctx.fill_uniform(0, "x", 11)
+    ctx.fill_uniform(1, "grad", 12)
+    ctx.aggregate(0, da.FORWARD)
+    ctx.aggregate(1, da.BACKWARD)
+    rng = np.random.default_rng(0)
+    deg = np.diff(g["colPtr"].astype(np.int64))
+    rows = np.unique(np.concatenate([rng.integers(0, N, 1500), np.argsort(deg)[-10:], [0, N - 1]]))
+    X = ctx.download(0, "x")
+    ah = ctx.download(0, "ah")
+    assert X.nbytes > 2 ** 31
+    assert rel_err(ah[rows], _oracle_rows(g, "colPtr", "rowIdx", "cscVal", X, rows)) < 1e-4
+    w = g["norm"].astype(np.float64) + np.bincount(g["rowIdx"], weights=g["cscVal"].astype(np.float64), minlength=N)
+    expect = w @ X.astype(np.float64)
+    got = ah.astype(np.float64).sum(0)
+    assert np.abs(got - expect).max() / np.abs(expect).max() < 1e-5
+    G1 = ctx.download(1, "grad")
+    aTg = ctx.download(0, "aTg")
+    assert rel_err(aTg[rows], _oracle_rows(g, "rowPtr", "colIdx", "csrVal", G1, rows)) < 1e-4
+    ctx.upload(0, "x", X * np.float32(2.0))
+    ctx.aggregate(0, da.FORWARD)
+    assert np.array_equal(ctx.download(0, "ah"), ah * np.float32(2.0))
+    del X, ah, G1, aTg
+    ctx.fill_uniform(0, "x", 1)
+    ctx.labels_upload(np.random.default_rng(2).integers(0, dims[-1], N).astype(np.uint32))
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    losses = []
+    for _ in range(3):
+        eng.run(1)
+        a, l, n = ctx.train_stat()
+        assert np.isfinite(l) and n == int(N * 0.1)
+        losses.append(l / n)
+    assert losses[-1] < losses[0]
+    for l in range(3):
+        assert np.isfinite(ctx.weight_get(l)).all()
+    eng.close()
+    ctx.close()

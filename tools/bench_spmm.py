@@ -65,12 +65,12 @@ def main():
     for F in a.F:
         ctx = da.Context(0)
         ctx.configure(da.GCN, [F, 8, 4], N)
+        for kv in a.opt:                      # before the upload: some options shape the blocked adjacency
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
         ctx.graph_upload(g)
         ctx.preallocate()
         ctx.fill_uniform(0, "x", 1)
-        for kv in a.opt:
-            k, v = kv.split("=")
-            ctx.set_option(k, int(v))
         _, _, ld, _ = ctx.info(0, "x")
         comp = E * 8 + 8 * (N + 1) + 4 * N + 4 * F * N + 4 * F * N
         for variant in a.variants:

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(NT3) void spmm_sweep4_kernel(SpmmArgs a, BlockedAdj
 template <int GROUP, int R, int U, bool GH, int FORM>
 __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj B, uint32_t rpx, uint32_t tiles_x, uint32_t G,
                                                           uint32_t *done /*[8][sweeps][nb][32] + flag*/, uint32_t nsweeps,
-                                                          int slack, int prefetch, int lag_w, int lag_g) {
+                                                          int slack, int prefetch, int lag_w, int lag_g, unsigned long long *tacc) {
     constexpr int GPW = 64 / GROUP;
     constexpr int NGRP = NT3 / GROUP;
     constexpr int NW = NT3 / 64;
@@ -569,7 +569,9 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
         }
     }
 
+    unsigned long long t_gate = 0, t_stage = 0, t_rows = 0, t_post = 0;
     for (uint32_t b = 0; b < B.nb; ++b) {
+        unsigned long long tq0 = wall_clock64();
         // gate: start step b only when every workgroup has finished step b-slack-1 (of this sweep or the previous one)
         {
             const int bb = (int)b - slack - 1;
@@ -603,6 +605,8 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
                 }
             }
         }
+        unsigned long long tq1 = wall_clock64();
+        t_gate += tq1 - tq0;
         // (1) offsets of step b+1 and this workgroup's share of window b+1 (one 128-B line per lane)
         uint32_t my_o_next = 0;
         if (b + 1 < B.nb) my_o_next = (B.boff + (size_t)(b + 1) * (a.N + 1))[min(v0 + (uint32_t)min(li, R), xend)];
@@ -640,6 +644,8 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
                     }
                 }
             }
+            unsigned long long tq2 = wall_clock64();
+            t_stage += tq2 - tq1;
             auto rowp = [&](uint32_t sidx) -> const float4 * {
                 return ((!GH || sidx < a.N) ? xl4 + (size_t)sidx * nchunk : xg4 + (size_t)(sidx - a.N) * nchunk) + ccol;
             };
@@ -702,6 +708,7 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
                 }
             }
         }
+        unsigned long long tq3 = wall_clock64();
         // (3) first chunk of step b+1's entries (in flight across the gate)
         my_o = my_o_next;
         if (b + 1 < B.nb) {
@@ -717,6 +724,7 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
             }
         }
         pf_sink += pf[0] + pf[1];
+        { unsigned long long tq4 = wall_clock64(); t_post += tq4 - tq3; t_rows += tq3 - tq1; }
         if (lane == 0) {   // the last wave to finish step b reports it
             const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[b & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == (uint32_t)(NW - 1 - lag_w))
@@ -724,6 +732,7 @@ __global__ __launch_bounds__(NT3) void spmm_sweep5_kernel(SpmmArgs a, BlockedAdj
             if (old == NW - 1) __hip_atomic_store(&lds_cnt[b & 7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    if (tacc && lane == 0) { atomicAdd(tacc + 0, t_gate); atomicAdd(tacc + 1, t_stage); atomicAdd(tacc + 2, t_rows); atomicAdd(tacc + 3, t_post); atomicAdd(tacc + 4, 1ull); }
     (void)NGv;
     if (pf_sink == 1.2345e-30f) a.out[0] = pf_sink;   // keeps the prefetch loads alive
     float4 *out4 = reinterpret_cast<float4 *>(a.out);
@@ -772,6 +781,7 @@ static void launch_sweep4(const SpmmArgs &a, const BlockedAdj &B, uint32_t *done
                        tiles_x, G, done, nsweeps, slack, prefetch, lag_w, lag_g);
 }
 
+static unsigned long long *g_tacc = nullptr;
 template <int GROUP, int R, int U, int FORM>
 static void launch_sweep5(const SpmmArgs &a, const BlockedAdj &B, uint32_t *done, int slack, int prefetch, hipStream_t s,
                           int lag_w = 0, int lag_g = 0) {
@@ -785,7 +795,7 @@ static void launch_sweep5(const SpmmArgs &a, const BlockedAdj &B, uint32_t *done
     const uint32_t nsweeps = slabs * spp;
     CK(hipMemsetAsync(done, 0, ((size_t)8 * nsweeps * B.nb * 32 + 1) * 4, s));
     hipLaunchKernelGGL((spmm_sweep5_kernel<GROUP, R, U, false, FORM>), dim3(8 * slabs * tiles_pad), dim3(NT3), 0, s, a, B, rpx,
-                       tiles_x, G, done, nsweeps, slack, prefetch, lag_w, lag_g);
+                       tiles_x, G, done, nsweeps, slack, prefetch, lag_w, lag_g, g_tacc);
 }
 
 template <int GROUP, int R, int U>
@@ -900,7 +910,8 @@ int main(int argc, char **argv) {
     }
     uint32_t *d_done;
     CK(hipMalloc(&d_done, 64 << 20));
-    for (uint32_t nb : {48u, 64u}) {
+    CK(hipMalloc(&g_tacc, 64));
+    for (uint32_t nb : {48u}) {
         BlockedAdj B{};
         CK(build_blocked(d_ptr, d_idx, d_val, N, N, E, nb, 512, &B, 0));
 #define RUN(GR, R, U, SYNC)                                                                                       \
@@ -949,18 +960,18 @@ int main(int argc, char **argv) {
 #define RUN5(GR, R, U, FORM)                                                                                      \
     do {                                                                                                          \
         CK(hipMemset(d_out, 0, (size_t)N * ld * 4));                                                              \
+        CK(hipMemset(g_tacc, 0, 64));                                                                             \
         float t = time_ms([&] { launch_sweep5<GR, R, U, FORM>(a, B, d_done, 1, 0, 0); });                         \
+        { unsigned long long h[5]; CK(hipMemcpy(h, g_tacc, 40, hipMemcpyDeviceToHost));                           \
+          const double nwv = (double)h[4];                                                                        \
+          printf("   per wave (mean over %.0f waves x 4 launches): gate %.2f ms, stage %.2f ms, rows+stage %.2f ms, post %.2f ms (100 MHz ticks)\n", nwv, \
+                 h[0] / nwv * 1e-5, h[1] / nwv * 1e-5, h[2] / nwv * 1e-5, h[3] / nwv * 1e-5); }                    \
         CK(hipMemcpy(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost));                                \
         printf("K1s5 nb=%3u window %.2f MB group %d R=%d U=%d form %d: %.3f ms  gather %.2f TB/s  err %.2e\n",    \
                B.nb, (double)B.SB * GR * 16 / 1048576.0, GR, R, U, FORM, t, gather / t / 1e9, rel_err(hout, href)); \
         fflush(stdout);                                                                                           \
     } while (0)
-        RUN4L(32, 10, 4, 1, 0, 0);
         RUN5(32, 10, 4, 0);
-        RUN5(32, 10, 8, 0);
-        RUN5(32, 10, 2, 1);
-        RUN5(32, 10, 4, 1);
-        RUN5(32, 8, 4, 0);
         if (false) {
             unsigned long long *d_dbg;
             const size_t nd = (size_t)2048 * 64 * 2;
