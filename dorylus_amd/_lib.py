@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdorylus_hip.so")
+LIB_PATH = os.environ.get("DORY_LIB_PATH") or os.path.join(_HERE, "libdorylus_hip.so")   # DORY_LIB_PATH: A/B runs against another build
 
 # every symbol include/dorylus_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [

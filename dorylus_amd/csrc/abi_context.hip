@@ -155,7 +155,8 @@ int dory_create(int device, dory_ctx **out) {
     (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
-    c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (tried and dropped: warming the next window from waves that wait at a gate, 14.1 -> 15.3 ms)
+    c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
+    c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
     c->opt["spmm_slab"] = 0;
@@ -192,6 +193,9 @@ static void free_graph(dory_ctx *c) {
     }
     free_blocked(&c->blkIn);
     free_blocked(&c->blkOut);
+    free_blocked(&c->swpIn);
+    free_blocked(&c->swpOut);
+    c->swpIn_built = c->swpOut_built = c->swpIn_na = c->swpOut_na = false;
     c->blkIn_built = c->blkOut_built = false;
     c->blkIn_na = c->blkOut_na = false;
     c->has_graph = false;
@@ -490,18 +494,31 @@ int dory_preallocate(dory_ctx *c) {
         uint32_t maxld = 0;
         for (uint32_t l = 0; l <= L; ++l) maxld = std::max(maxld, pad_ld(d[l]));
         const int group = blk_group_for(c, maxld);   // block size for the widest rows (most of the traffic)
-        if (minld >= 32) {
+        if (minld >= 32 && c->opt["spmm_variant"] == 2) {
+            // K1s: its layouts and the gate counters of the largest launch now, so that nothing is built or allocated
+            // inside an epoch (a partition it does not take -- too small, too large -- keeps K1 / builds K1b on demand)
+            if ((rc = ensure_sweep(c, true, group))) return rc;
+            if ((rc = ensure_sweep(c, false, group))) return rc;
+            size_t need = 0;
+            for (const BlockedAdj *S : {&c->swpIn, &c->swpOut})
+                if (S->nb) {
+                    SpmmArgs sa{};
+                    sa.N = S->npos; sa.ld = maxld;
+                    need = std::max(need, sweep_scratch_bytes(sa, group, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb));
+                }
+            if (need > c->partial_bytes) {
+                if (c->partial) (void)hipFree(c->partial);
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIPCK(c, hipMalloc((void **)&c->partial, need));
+                c->partial_bytes = need;
+            }
+        } else if (minld >= 32) {
             if ((rc = ensure_blocked(c, true, group))) return rc;
             if ((rc = ensure_blocked(c, false, group))) return rc;
             // the partial-sum buffer too, so that no allocation happens inside an epoch
             const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
-            size_t need = (size_t)nbmax * N * maxld * sizeof(float);
-            if (c->opt["spmm_variant"] == 2 && nbmax && !c->blkIn.nchunks && !c->blkOut.nchunks) {
-                // K1s keeps its sums in registers: only the gate counters of the largest launch
-                SpmmArgs sa{};
-                sa.N = N; sa.ld = maxld;
-                need = sweep_scratch_bytes(sa, group, std::min<uint32_t>(32u, c->cus_per_xcd), nbmax);
-            }
+            const size_t need = (size_t)nbmax * N * maxld * sizeof(float);
             if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
                 if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;

@@ -74,6 +74,7 @@ Tensor *find(dory_ctx *c, uint32_t layer, const char *name);
 Tensor *findw(std::vector<std::map<std::string, Tensor>> &tab, uint32_t layer, const char *name);
 void free_table(std::vector<std::map<std::string, Tensor>> &tab);
 int ensure_scratch(dory_ctx *c, size_t bytes);
+int ensure_sweep(dory_ctx *c, bool csc, int group);
 // drops a recorded epoch (hipGraph): anything that frees or moves what the recorded kernels point at calls this
 void epoch_graph_drop_locked(dory_ctx *c);
 std::vector<uint32_t> degree_order(const uint64_t *ptr, uint32_t N);

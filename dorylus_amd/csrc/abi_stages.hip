@@ -22,8 +22,7 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         // K1b pays nb partial rows per output row: only worth it (and only affordable: the
         // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
         // hundred L2 windows at most.  Larger partitions keep K1.
-        // K1s (spmm_variant 2) wants two windows in one 4 MB L2; K1b and the multi-head GAT kernels were tuned on ~5 MB
-        const uint64_t window = (c->opt["spmm_variant"] == 2 && c->gnn != DORY_GATMH) ? (uint64_t)c->opt["spmm_sweep_window_kb"] << 10 : 0;
+        const uint64_t window = 0;   // K1b's own windows (K1s has its own layout: ensure_sweep)
         const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u, window);
         // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
         // K1 then gathers from L2 without partial sums or a second kernel
@@ -36,21 +35,41 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         }
         HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
                                c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute, window));
-        if (window && B.nchunks) {
-            // hub (block,row) segments: K1s does not take them (a long segment on one lane group would hold up every
-            // workgroup of its XCD at the gate); K1b does, with its own window size
-            free_blocked(&B);
-            const uint32_t nb1 = plan_blocks(NG, want_nb, (uint32_t)group * 16u, 0);
-            if (nb1 > 256 || (uint64_t)nb1 * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
-                (csc ? c->blkIn_na : c->blkOut_na) = true;
-                return DORY_OK;
-            }
-            HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
-                                   c->N, NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, &B, c->compute, 0));
-        }
         B.row_bytes = (uint32_t)group * 16u;
         built = true;
     }
+    return DORY_OK;
+}
+
+// K1s bookkeeping: the even layout build_blocked_sweep makes of one adjacency (spmm.hip)
+int ensure_sweep(dory_ctx *c, bool csc, int group) {
+    BlockedAdj &S = csc ? c->swpIn : c->swpOut;
+    bool &built = csc ? c->swpIn_built : c->swpOut_built;
+    bool &na = csc ? c->swpIn_na : c->swpOut_na;
+    const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
+    if (built && want_nb && S.nb != want_nb && !c->capturing) {     // an explicit block count (tests) forces a rebuild
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        free_blocked(&S);
+        built = false;
+    }
+    if (built || na) return DORY_OK;
+    if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: the sweep layout would have to be built while recording");
+    const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
+    const uint64_t window = (uint64_t)c->opt["spmm_sweep_window_kb"] << 10;
+    const uint64_t nb_est = ((uint64_t)NG * group * 16u + window - 1) / window + 1;
+    // the whole source slab in one L2 (Cora-sized graphs): K1 gathers from L2 anyway.  Thousands of windows (Amazon-,
+    // Friendster-sized partitions on a random graph: a row has a fraction of an edge per window): the per-(block,
+    // position) offset table alone would be nb*(N+1) words -- K1
+    const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20);
+    if (tiny || c->N < 8 || (want_nb ? want_nb : nb_est) > 512 || (want_nb ? want_nb : nb_est) * (uint64_t)(c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
+        na = true;
+        return DORY_OK;
+    }
+    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd));   // the deal is made for the 32-lane launches
+    HIPCK(c, build_blocked_sweep(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal, c->N,
+                                 NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, window, R, &S, c->compute,
+                                 (uint32_t)c->opt["spmm_sweep_layout"]));
+    built = true;
     return DORY_OK;
 }
 
@@ -80,19 +99,20 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.accumulate = accumulate;
     a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
     const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal
-    if (c->opt["spmm_variant"] >= 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+    if (c->opt["spmm_variant"] == 2 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+        // K1s: register accumulators, every workgroup sweeps all source blocks of its own even layout (spmm.hip).
         const int group = blk_group_for(c, a.ld);
-        int rc = ensure_blocked(c, csc, group);
+        int rc = ensure_sweep(c, csc, group);
         if (rc) return rc;
-        BlockedAdj &B = csc ? c->blkIn : c->blkOut;
-        if (c->opt["spmm_variant"] == 2 && !(csc ? c->blkIn_na : c->blkOut_na) && sweep_supported(a, B, group)) {
-            // K1s: register accumulators, every workgroup sweeps all source blocks (spmm.hip).  With ghost rows the blocks
-            // that hold local rows only always run as a launch of their own (they do not depend on an exchange in
-            // flight), so the overlapped and the sequential schedule are the same arithmetic.
+        BlockedAdj &S = csc ? c->swpIn : c->swpOut;
+        if (!(csc ? c->swpIn_na : c->swpOut_na) && sweep_supported(a, S, group)) {
             const uint32_t G = std::min<uint32_t>(32u, c->cus_per_xcd);
-            const uint32_t nb_local = std::min(B.nb, c->N / B.SB);
-            const bool two = a.xg != nullptr && nb_local > 0 && nb_local < B.nb;
-            const size_t need = sweep_scratch_bytes(a, group, G, two ? std::max(nb_local, B.nb - nb_local) : B.nb);
+            // With ghost rows the blocks that hold local rows only always run as a launch of their own (they do not
+            // depend on an exchange in flight), so the overlapped and the sequential schedule are the same arithmetic.
+            const bool two = a.xg != nullptr && S.nb_local > 0 && S.nb_local < S.nb;
+            SpmmArgs sa = a;
+            sa.N = S.npos;
+            const size_t need = sweep_scratch_bytes(sa, group, G, two ? std::max(S.nb_local, S.nb - S.nb_local) : S.nb);
             if (need > c->partial_bytes) {
                 if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: sweep counters would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));
@@ -102,22 +122,31 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 HIPCK(c, hipMalloc((void **)&c->partial, need));
                 c->partial_bytes = need;
             }
+            if (S.nslots && (rc = ensure_scratch(c, (size_t)S.nslots * a.ld * sizeof(float)))) return rc;   // pieces of split rows
             Timed t(c, "spmm", c->compute);
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
             const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+            SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
             if (two) {
-                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, nb_local, done, c->compute, sflags));
+                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, sflags, c->scratch));
                 if ((rc = wait_halo(c))) return rc;
                 SpmmArgs a2 = a;
                 a2.self_mode = 0;
                 a2.accumulate = 1;
-                HIPCK(c, launch_spmm_sweep(a2, B, group, row_scale, G, nb_local, B.nb, done, c->compute, sflags));
+                HIPCK(c, launch_spmm_sweep(a2, S, group, row_scale, G, S.nb_local, S.nb, done, c->compute, sflags | 2u, c->scratch));
             } else {
                 if ((rc = wait_halo(c))) return rc;
-                HIPCK(c, launch_spmm_sweep(a, B, group, row_scale, G, 0, B.nb, done, c->compute, sflags));
+                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb, done, c->compute, sflags, c->scratch));
             }
+            HIPCK(c, launch_spmm_sweep_combine(a, S, row_scale, c->scratch, c->compute));
             return DORY_OK;
         }
+    }
+    if (c->opt["spmm_variant"] >= 1 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
+        const int group = blk_group_for(c, a.ld);
+        int rc = ensure_blocked(c, csc, group);
+        if (rc) return rc;
+        BlockedAdj &B = csc ? c->blkIn : c->blkOut;
         const size_t need = blocked_partial_bytes(a, B);
         if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
             if (need > c->partial_bytes) {

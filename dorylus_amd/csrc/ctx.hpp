@@ -46,6 +46,14 @@ struct BlockedAdj {
     uint32_t nb = 0;        // number of source blocks (multiple of 8: one per XCD per round)
     uint32_t SB = 0;        // rows per block
     uint32_t row_bytes = 0; // slab bytes per row the block size was chosen for
+    uint32_t npos = 0;      // destination positions = leading dimension of boff minus 1 (N, or more with `perm`)
+    uint32_t nb_local = 0;  // blocks [0, nb_local) contain local source rows only
+    // K1s layout (build_blocked_sweep): destination positions are a degree-balanced deal of the rows (rows of very high
+    // degree cut into pieces), source rows are spread over the blocks by a random permutation (local / ghost rows apart)
+    uint32_t *perm = nullptr;        // npos: position -> row, 0xFFFFFFFF = empty; nullptr = identity
+    uint32_t *otgt = nullptr;        // npos: where a position's sum goes: the row, or 0x80000000 | slot for a piece of a split row
+    uint32_t *split_rows = nullptr;  // 3 words per split row: row, first slot, pieces
+    uint32_t nsplit = 0, nslots = 0;
     uint64_t *bbase = nullptr;  // nb+1: first edge of each block
     uint32_t *boff = nullptr;   // [nb][N+1]: row offsets inside the block
     uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order
@@ -112,6 +120,8 @@ struct dory_ctx {
     dory::LongRowsDev longIn, longOut;          // K1: hub rows of forwardAdj / backwardAdj
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
+    dory::BlockedAdj swpIn, swpOut;             // K1s layouts (built on first use when spmm_variant == 2)
+    bool swpIn_built = false, swpOut_built = false, swpIn_na = false, swpOut_na = false;
     bool blkIn_built = false, blkOut_built = false;
     bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
     uint32_t cus_per_xcd = 32;                  // K1s: workgroups per sweep
@@ -204,12 +214,18 @@ hipError_t launch_spmm_blocked_long_segments(const SpmmArgs &a, const BlockedAdj
 hipError_t launch_spmm_blocked_reduce(const SpmmArgs &a, const BlockedAdj &B, const float *partial,
                                       const float *row_scale, hipStream_t s);
 void free_blocked(BlockedAdj *B);
-// K1s: the register-accumulating sweep over the same blocked adjacency (spmm.hip)
+// K1s: the register-accumulating sweep over its own even layout of the blocked adjacency (spmm.hip)
+hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
+                               uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
+                               BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */);
+int sweep_pick_r(uint32_t N, int group, uint32_t G);
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s,
-                             uint32_t flags = 0);
+                             uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */);
+hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
+                                     hipStream_t s);
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
                                const float *row_scale /*nullable: unit edge weights, per-row factor*/, hipStream_t s);

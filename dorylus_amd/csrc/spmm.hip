@@ -22,6 +22,7 @@
 //     keeps the gathered working set N x slab x 4 B small enough for the 256 MB
 //     Infinity Cache.
 //   * optional row schedule (longest row first) for skewed degree distributions.
+#include <algorithm>
 #include <vector>
 
 #include "ctx.hpp"
@@ -307,11 +308,22 @@ hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s) 
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vector for nontemporal ld/st
 constexpr int BLK_ROWS = 32;             // destination rows per workgroup (64: +2.5 % time, 16: same, 128: +6 %)
 
+// `perm` (optional): position -> row (0xFFFFFFFF = empty position); `sblk` (optional): source row -> block.  Without
+// them position = row and block = source / SB (K1b's layout); with them the K1s layout of build_blocked_sweep.
 __global__ __launch_bounds__(256) void blk_count_kernel(uint32_t N, const uint64_t *ptr, const uint32_t *idx,
-                                                        uint32_t SB, uint32_t *cnt /*[nb][N]*/) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) cnt[(size_t)(idx[e] / SB) * N + v] += 1;
+                                                        uint32_t SB, uint32_t *cnt /*[nb][N]*/, const uint32_t *perm,
+                                                        const uint16_t *sblk, const uint2 *slice) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t v = perm ? perm[p] : p;
+    if (v == 0xFFFFFFFFu) return;
+    uint64_t e0 = ptr[v], e1 = ptr[v + 1];
+    if (slice && slice[p].y > 1) {   // piece k of K of a split row: a contiguous range of its edge list
+        const uint64_t chunk = (e1 - e0 + slice[p].y - 1) / slice[p].y;
+        e0 = min(e1, e0 + (uint64_t)slice[p].x * chunk);
+        e1 = min(e1, e0 + chunk);
+    }
+    for (uint64_t e = e0; e < e1; ++e) cnt[(size_t)(sblk ? (uint32_t)sblk[idx[e]] : idx[e] / SB) * N + p] += 1;
 }
 
 // one workgroup per block b: boff[b][0..N] = exclusive scan of cnt[b][0..N), total[b]
@@ -349,14 +361,23 @@ __global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, 
                                                        const uint32_t *idx, const float *val, uint32_t SB,
                                                        const uint64_t *bbase, const uint32_t *boff,
                                                        uint32_t *cursor /*[nb][N] scratch*/, uint32_t *bidx,
-                                                       float *bval) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    for (uint32_t b = 0; b < nb; ++b) cursor[(size_t)b * N + v] = boff[(size_t)b * (N + 1) + v];
-    for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e) {   // original order inside each (block,row) segment
+                                                       float *bval, const uint32_t *perm, const uint16_t *sblk,
+                                                       const uint2 *slice) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t v = perm ? perm[p] : p;
+    if (v == 0xFFFFFFFFu) return;
+    for (uint32_t b = 0; b < nb; ++b) cursor[(size_t)b * N + p] = boff[(size_t)b * (N + 1) + p];
+    uint64_t e0 = ptr[v], e1 = ptr[v + 1];
+    if (slice && slice[p].y > 1) {
+        const uint64_t chunk = (e1 - e0 + slice[p].y - 1) / slice[p].y;
+        e0 = min(e1, e0 + (uint64_t)slice[p].x * chunk);
+        e1 = min(e1, e0 + chunk);
+    }
+    for (uint64_t e = e0; e < e1; ++e) {   // original order inside each (block,row) segment
         const uint32_t s = idx[e];
-        const uint32_t b = s / SB;
-        const uint64_t pos = bbase[b] + cursor[(size_t)b * N + v]++;
+        const uint32_t b = sblk ? (uint32_t)sblk[s] : s / SB;
+        const uint64_t pos = bbase[b] + cursor[(size_t)b * N + p]++;
         bidx[pos] = s;
         bval[pos] = val[e];
     }
@@ -382,6 +403,8 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
     const uint32_t nb = plan_blocks(NG, want_nb, row_bytes, window_bytes);
     B.nb = nb;
     B.SB = (NG + nb - 1) / nb;
+    B.npos = N;
+    B.nb_local = std::min(nb, N / B.SB);
     uint32_t *cnt = nullptr;
     hipError_t e;
 #define BCK(x) if ((e = (x)) != hipSuccess) return e
@@ -393,7 +416,8 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
     BCK(hipMalloc((void **)&B.bval, (nnz ? nnz : 1) * sizeof(float)));
     uint64_t *dtotal = nullptr;
     BCK(hipMalloc((void **)&dtotal, nb * sizeof(uint64_t)));
-    hipLaunchKernelGGL(blk_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ptr, idx, B.SB, cnt);
+    hipLaunchKernelGGL(blk_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ptr, idx, B.SB, cnt,
+                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, (const uint2 *)nullptr);
     hipLaunchKernelGGL(blk_scan_kernel, dim3(nb), dim3(1024), 0, s, N, cnt, B.boff, dtotal);
     std::vector<uint64_t> tot(nb), base(nb + 1, 0);
     BCK(hipMemcpyAsync(tot.data(), dtotal, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -402,7 +426,8 @@ hipError_t build_blocked(const uint64_t *ptr, const uint32_t *idx, const float *
     if (base[nb] != nnz) return hipErrorUnknown;
     BCK(hipMemcpyAsync(B.bbase, base.data(), (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(blk_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nb, ptr, idx, val, B.SB,
-                       B.bbase, B.boff, cnt, B.bidx, B.bval);
+                       B.bbase, B.boff, cnt, B.bidx, B.bval, (const uint32_t *)nullptr, (const uint16_t *)nullptr,
+                       (const uint2 *)nullptr);
     BCK(hipGetLastError());
     BCK(hipStreamSynchronize(s));
     (void)hipFree(cnt);
@@ -451,7 +476,7 @@ void free_blocked(BlockedAdj *B) {
     if (B->bbase) (void)hipFree(B->bbase);
     if (B->bidx) (void)hipFree(B->bidx);
     if (B->bval) (void)hipFree(B->bval);
-    for (uint32_t *q : {B->seg_row, B->seg_blk, B->seg_chunk_ptr, B->seg_chunks})
+    for (uint32_t *q : {B->seg_row, B->seg_blk, B->seg_chunk_ptr, B->seg_chunks, B->perm, B->otgt, B->split_rows})
         if (q) (void)hipFree(q);
     *B = BlockedAdj{};
 }
@@ -756,7 +781,8 @@ struct SweepArgs {
     uint32_t nsweeps;    // slabs * ceil(tiles_x / G)
     uint32_t b_lo, b_hi; // source blocks of this launch
     uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
-    uint32_t flags;      // reserved for experiments (none active)
+    uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots)
+    float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
 };
 
 template <int GROUP, int R, bool UNIT, bool GH>
@@ -788,7 +814,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % GROUP, gi = lane / GROUP;
     const int g = wave * GPW + gi;
-    const uint32_t xend = min((xcd + 1) * w.rpx, a.N);
+    const uint32_t xend = min((xcd + 1) * w.rpx, B.npos);   // positions (= rows without B.perm)
     const uint32_t v0 = min(xcd * w.rpx + t * RW + (uint32_t)g * R, xend);
     const uint32_t nchunk = a.ld >> 2;
     const uint32_t col = slab * GROUP + li;
@@ -822,7 +848,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         }
     };
 
-    uint32_t my_o = (B.boff + (size_t)w.b_lo * (a.N + 1))[orow];
+    uint32_t my_o = (B.boff + (size_t)w.b_lo * (B.npos + 1))[orow];
     uint2 en_pre[CQ];
     load_entries(w.b_lo, my_o, en_pre);
 
@@ -864,7 +890,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         }
         // offsets of the next step (in flight during this one)
         uint32_t my_o_next = 0;
-        if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (a.N + 1))[orow];
+        if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (B.npos + 1))[orow];
         if (li <= R) ol[li] = my_o;
         const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
         const uint64_t base = B.bbase[b];
@@ -928,31 +954,223 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         }
     }
 
+    // one store path for rows and for pieces of split rows (a piece: the bare sum into its slot, no scale, no self
+    // term; spmm_sweep_combine_kernel finishes those rows)
     float4 *out4 = reinterpret_cast<float4 *>(a.out);
+    float4 *part4 = reinterpret_cast<float4 *>(w.split_partial);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const uint32_t v = v0 + r;
-        if (v < xend && col_ok) {
-            float4 o4 = acc[r];
-            if (row_scale) {
-                const float rs = row_scale[v];
-                o4 = make_float4(o4.x * rs, o4.y * rs, o4.z * rs, o4.w * rs);
+        const uint32_t pos = v0 + r;
+        const uint32_t v = pos < xend ? (B.perm ? B.perm[pos] : pos) : 0xFFFFFFFFu;
+        if (v != 0xFFFFFFFFu && col_ok) {
+            const uint32_t tgt = B.otgt ? B.otgt[pos] : v;
+            const bool piece = (tgt & 0x80000000u) != 0;
+            float4 *q = piece ? part4 + (size_t)(tgt & 0x7FFFFFFFu) * nchunk + col : out4 + (size_t)v * nchunk + col;
+            const float rs = (row_scale && !piece) ? row_scale[v] : 1.f;
+            float sc = 0.f;
+            float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.self_mode != 0 && !piece) {
+                sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+                xs = xl4[(size_t)v * nchunk];
             }
-            if (a.self_mode != 0) {
-                const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
-                o4 = fma4(sc, xl4[(size_t)v * nchunk], o4);
-            }
-            if (a.accumulate) {
-                const float4 p = out4[(size_t)v * nchunk + col];
+            float4 o4 = make_float4(acc[r].x * rs, acc[r].y * rs, acc[r].z * rs, acc[r].w * rs);
+            o4 = fma4(sc, xs, o4);
+            if (piece ? (w.flags & 2u) != 0 : a.accumulate != 0) {   // second launch / caller's out += result
+                const float4 p = *q;
                 o4.x += p.x; o4.y += p.y; o4.z += p.z; o4.w += p.w;
             }
-            out4[(size_t)v * nchunk + col] = o4;
+            *q = o4;
         }
     }
 }
 
+// out[row] (+)= self + (row_scale *) sum of the row's pieces, in piece order (one workgroup per split row)
+__global__ __launch_bounds__(256) void spmm_sweep_combine_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
+                                                                 const float *split_partial) {
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t v = B.split_rows[3 * blockIdx.x], s0 = B.split_rows[3 * blockIdx.x + 1], K = B.split_rows[3 * blockIdx.x + 2];
+    const float4 *p4 = reinterpret_cast<const float4 *>(split_partial) + (size_t)s0 * nchunk;
+    const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
+    float4 *out4 = reinterpret_cast<float4 *>(a.out) + (size_t)v * nchunk;
+    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t k = 0; k < K; ++k) {
+            const float4 t = p4[(size_t)k * nchunk + col];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (row_scale) {
+            const float rs = row_scale[v];
+            acc = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
+        }
+        if (a.self_mode != 0) {
+            const float sc = a.self_mode == 1 ? a.self_scale[v] : 1.f;
+            acc = fma4(sc, xl4[(size_t)v * nchunk + col], acc);
+        }
+        if (a.accumulate) {
+            const float4 p = out4[col];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        out4[col] = acc;
+    }
+}
+
+hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
+                                     hipStream_t s) {
+    if (!B.nsplit || a.ld == 0) return hipSuccess;
+    hipLaunchKernelGGL(spmm_sweep_combine_kernel, dim3(B.nsplit), dim3(256), 0, s, a, B, row_scale, split_partial);
+    return hipGetLastError();
+}
+
+// ---- the K1s layout ------------------------------------------------------------------------------------------------
+// K1s keeps all workgroups of an XCD in step, so a step costs what its slowest lane group needs.  On a graph without
+// structure the per-(block,row) segments are Poisson and the groups are even; with skewed degrees or with locality
+// (communities of consecutive ids: a row's edges sit in one block) they are not -- measured with K1b's layout:
+// power-law 50.9 ms against K1b's 28.9.  The layout K1s sweeps is therefore made even by construction:
+//   * source rows are spread over the blocks by a seeded random permutation, local rows over blocks [0, nb_local) and
+//     ghost rows over the rest (so the blocks that need no ghosts still come first); a window is then a scattered set
+//     of rows -- the L2 does not care;
+//   * destination rows are sorted by degree and dealt into positions, R bands of descending degree, alternate bands
+//     in reverse (serpentine), so that every R consecutive positions (one lane group) carry nearly the same number of
+//     edges.  A row whose degree is more than SWEEP_SPLIT x the mean cannot be evened out that way (and a hub would
+//     hold up every workgroup of its XCD at every gate): it is cut into pieces of about that many edges (contiguous
+//     ranges of its edge list), each piece is a position of its own whose bare sum lands in a slot of a small side
+//     buffer, and spmm_sweep_combine_kernel adds a row's pieces in piece order (deterministic), scales, adds the
+//     self term and writes the row.
+constexpr uint32_t SWEEP_SPLIT = 2;
+
+hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
+                               uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
+                               BlockedAdj *out, hipStream_t s, uint32_t layout) {
+    BlockedAdj B{};
+    if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
+    hipError_t e;
+#define BCK(x) if ((e = (x)) != hipSuccess) return e
+    std::vector<uint64_t> hptr((size_t)N + 1);
+    BCK(hipMemcpyAsync(hptr.data(), ptr, ((size_t)N + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    BCK(hipStreamSynchronize(s));
+    // destination side: pieces of rows, dealt by their edge count
+    const uint64_t split_deg = std::max<uint64_t>(64, (uint64_t)SWEEP_SPLIT * (nnz / N + 1));
+    struct Item { uint32_t row, k, K; uint64_t w; };
+    std::vector<Item> items;
+    items.reserve(N);
+    std::vector<uint32_t> split_rows;       // (row, first slot, K) per split row
+    uint32_t nslots = 0;
+    for (uint32_t v = 0; v < N; ++v) {
+        const uint64_t deg = hptr[v + 1] - hptr[v];
+        if (deg > split_deg) {
+            const uint64_t K64 = (deg + split_deg - 1) / split_deg;
+            if (K64 > 0x7FFFFFFFull || (uint64_t)nslots + K64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+            const uint32_t K = (uint32_t)K64;
+            split_rows.insert(split_rows.end(), {v, nslots, K});
+            for (uint32_t k = 0; k < K; ++k) items.push_back({v, k, K, (deg + K - 1) / K});
+            nslots += K;
+        } else {
+            items.push_back({v, 0, 1, deg});
+        }
+    }
+    if (layout & 2u) std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.w > y.w; });
+    const uint64_t ni64 = items.size();
+    if (ni64 + 16 > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const uint32_t nl = (uint32_t)ni64;
+    const uint32_t T = (nl + R - 1) / (uint32_t)R;              // lane groups
+    const uint32_t npos = std::max<uint32_t>(T * (uint32_t)R, 8);
+    std::vector<uint32_t> perm(npos, 0xFFFFFFFFu), otgt;
+    std::vector<uint2> slice;
+    if (nslots) { otgt.assign(npos, 0xFFFFFFFFu); slice.assign(npos, make_uint2(0u, 1u)); }
+    {
+        std::vector<uint32_t> slot0(nslots ? N : 0, 0);
+        for (size_t q = 0; q < split_rows.size(); q += 3) slot0[split_rows[q]] = split_rows[q + 1];
+        for (uint32_t i = 0; i < nl; ++i) {
+            const uint32_t band = i / T, j = i % T;
+            const uint32_t jj = (band & 1u) ? T - 1 - j : j;
+            const size_t pos = (layout & 2u) ? (size_t)jj * R + band : (size_t)i;
+            perm[pos] = items[i].row;
+            if (nslots) {
+                slice[pos] = make_uint2(items[i].k, items[i].K);
+                otgt[pos] = items[i].K > 1 ? (0x80000000u | (slot0[items[i].row] + items[i].k)) : items[i].row;
+            }
+        }
+    }
+    // source side: block of every source row
+    const uint32_t G = NG - N;
+    const uint64_t window = window_bytes ? window_bytes : (uint64_t)2432 << 10;
+    uint32_t nbL = (uint32_t)(((uint64_t)N * row_bytes + window - 1) / window), nbG = G ? (uint32_t)(((uint64_t)G * row_bytes + window - 1) / window) : 0;
+    if (want_nb) {   // explicit block count (tests): split it in proportion, at least one block each
+        nbG = G ? std::max<uint32_t>(1, (uint32_t)((uint64_t)want_nb * G / NG)) : 0;
+        nbL = std::max<uint32_t>(1, want_nb > nbG ? want_nb - nbG : 1);
+    }
+    nbL = std::max<uint32_t>(nbL, 1);
+    const uint32_t nb = nbL + nbG;
+    if (nb > 65535) return hipErrorInvalidValue;
+    std::vector<uint16_t> sblk(NG);
+    {
+        uint64_t st = 0x9E3779B97F4A7C15ull ^ ((uint64_t)N << 20) ^ nnz;    // seeded: the layout is a pure function of the graph
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        auto spread = [&](uint32_t first, uint32_t count, uint32_t b0, uint32_t nblk) {
+            std::vector<uint32_t> pos(count);
+            for (uint32_t i = 0; i < count; ++i) pos[i] = i;
+            if (layout & 1u)
+                for (uint32_t i = count; i > 1; --i) std::swap(pos[i - 1], pos[rnd() % i]);   // Fisher-Yates
+            const uint32_t per = (count + nblk - 1) / nblk;
+            for (uint32_t i = 0; i < count; ++i) sblk[first + i] = (uint16_t)(b0 + pos[i] / per);
+        };
+        spread(0, N, 0, nbL);
+        if (G) spread(N, G, nbL, nbG);
+    }
+    B.nb = nb;
+    B.SB = (std::max(N, G) + std::max(nbL, std::max<uint32_t>(nbG, 1)) - 1) / std::max(nbL, std::max<uint32_t>(nbG, 1));   // rows per block (nominal)
+    B.npos = npos;
+    B.nb_local = nbL;
+    B.row_bytes = row_bytes;
+    uint32_t *cnt = nullptr;
+    uint16_t *d_sblk = nullptr;
+    uint64_t *dtotal = nullptr;
+    BCK(hipMalloc((void **)&B.perm, (size_t)npos * sizeof(uint32_t)));
+    BCK(hipMemcpyAsync(B.perm, perm.data(), (size_t)npos * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    BCK(hipMalloc((void **)&d_sblk, (size_t)NG * sizeof(uint16_t)));
+    BCK(hipMemcpyAsync(d_sblk, sblk.data(), (size_t)NG * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    uint2 *d_slice = nullptr;
+    if (nslots) {
+        BCK(hipMalloc((void **)&B.otgt, (size_t)npos * sizeof(uint32_t)));
+        BCK(hipMemcpyAsync(B.otgt, otgt.data(), (size_t)npos * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        BCK(hipMalloc((void **)&d_slice, (size_t)npos * sizeof(uint2)));
+        BCK(hipMemcpyAsync(d_slice, slice.data(), (size_t)npos * sizeof(uint2), hipMemcpyHostToDevice, s));
+        BCK(hipMalloc((void **)&B.split_rows, split_rows.size() * sizeof(uint32_t)));
+        BCK(hipMemcpyAsync(B.split_rows, split_rows.data(), split_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        B.nsplit = (uint32_t)(split_rows.size() / 3);
+        B.nslots = nslots;
+    }
+    BCK(hipMalloc((void **)&cnt, (size_t)nb * npos * sizeof(uint32_t)));
+    BCK(hipMemsetAsync(cnt, 0, (size_t)nb * npos * sizeof(uint32_t), s));
+    BCK(hipMalloc((void **)&B.boff, (size_t)nb * (npos + 1) * sizeof(uint32_t)));
+    BCK(hipMalloc((void **)&B.bbase, (size_t)(nb + 1) * sizeof(uint64_t)));
+    BCK(hipMalloc((void **)&B.bidx, (nnz ? nnz : 1) * sizeof(uint32_t)));
+    BCK(hipMalloc((void **)&B.bval, (nnz ? nnz : 1) * sizeof(float)));
+    BCK(hipMalloc((void **)&dtotal, nb * sizeof(uint64_t)));
+    hipLaunchKernelGGL(blk_count_kernel, dim3((npos + 255) / 256), dim3(256), 0, s, npos, ptr, idx, B.SB, cnt, B.perm, d_sblk,
+                       (const uint2 *)d_slice);
+    hipLaunchKernelGGL(blk_scan_kernel, dim3(nb), dim3(1024), 0, s, npos, cnt, B.boff, dtotal);
+    std::vector<uint64_t> tot(nb), base(nb + 1, 0);
+    BCK(hipMemcpyAsync(tot.data(), dtotal, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    BCK(hipStreamSynchronize(s));   // also: perm / sblk / heavy host vectors are free to go
+    for (uint32_t b = 0; b < nb; ++b) base[b + 1] = base[b] + tot[b];
+    if (base[nb] != nnz) return hipErrorUnknown;
+    BCK(hipMemcpyAsync(B.bbase, base.data(), (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(blk_fill_kernel, dim3((npos + 255) / 256), dim3(256), 0, s, npos, nb, ptr, idx, val, B.SB, B.bbase,
+                       B.boff, cnt, B.bidx, B.bval, B.perm, d_sblk, (const uint2 *)d_slice);
+    BCK(hipGetLastError());
+    BCK(hipStreamSynchronize(s));
+    (void)hipFree(cnt);
+    (void)hipFree(dtotal);
+    (void)hipFree(d_sblk);
+    if (d_slice) (void)hipFree(d_slice);
+#undef BCK
+    *out = B;
+    return hipSuccess;
+}
+
 // rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab
-static int sweep_pick_r(uint32_t N, int group, uint32_t G) {
+int sweep_pick_r(uint32_t N, int group, uint32_t G) {
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
     double best_fill = 0;
@@ -968,27 +1186,29 @@ static int sweep_pick_r(uint32_t N, int group, uint32_t G) {
 }
 
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
-    return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8;
+    return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8 && B.npos >= 8;
 }
 
 // counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
 size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks) {
+    // a.N stands for the number of destination positions here; the deal of build_blocked_sweep adds at most 8 * 10
     const int R = sweep_pick_r(a.N, group, G);
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
-    const uint32_t rpx = (a.N + 7) / 8, tiles = (rpx + RW - 1) / RW, spp = (tiles + G - 1) / G;
+    const uint32_t rpx = (a.N + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + G - 1) / G;
     const uint32_t slabs = ((a.ld >> 2) + group - 1) / group;
     return ((size_t)8 * slabs * spp * nblocks * 32 + 1) * sizeof(uint32_t);
 }
 
 // out (+)= self + (row_scale *) sum over source blocks [b_lo, b_hi); `done` = sweep_scratch_bytes() of device memory
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
-                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, uint32_t flags) {
+                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, uint32_t flags,
+                             float *split_partial) {
     if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
     if (!sweep_supported(a, B, group) || b_hi > B.nb || G == 0 || G > 32) return hipErrorInvalidValue;
-    const int R = sweep_pick_r(a.N, group, G);
+    const int R = sweep_pick_r(B.npos, group, G);
     SweepArgs w{};
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
-    w.rpx = (a.N + 7) / 8;
+    w.rpx = ((B.npos + 7) / 8 + R - 1) / R * R;   // whole lane groups per XCD
     w.tiles_x = (w.rpx + RW - 1) / RW;
     w.G = G;
     const uint32_t spp = (w.tiles_x + G - 1) / G;
@@ -997,7 +1217,9 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     w.b_lo = b_lo; w.b_hi = b_hi;
     w.done = done;
     w.flags = flags;
-    hipError_t e = hipMemsetAsync(done, 0, sweep_scratch_bytes(a, group, G, b_hi - b_lo), s);
+    w.split_partial = split_partial;
+    if (B.nslots && !split_partial) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(done, 0, ((size_t)8 * w.nsweeps * (b_hi - b_lo) * 32 + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const dim3 gr(8u * slabs * spp * G), bl(SWEEP_NT);
     const bool gh = a.xg != nullptr, unit = row_scale != nullptr;
