@@ -17,6 +17,14 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace -d /tmp/prof_${TAG}_$ctr -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_$ctr.log 2>&1
     python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_$ctr -name '*.db' | head -1)" > "$OUT/${TAG}_pmc_$(echo $ctr | tr A-Z a-z).txt" 2>&1
 done
+# further counter passes of the same command, each on its own (kernel trace only): MFMA busy cycles for the GEMMs,
+# L2 hit/miss and wave-state counters for the SpMM
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --kernel-trace -d /tmp/prof_${TAG}_set$i -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_set$i.log 2>&1
+    python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_set$i -name '*.db' | head -1)" > "$OUT/${TAG}_pmc_set$i.txt" 2>&1
+done
 cd "$R"
 python bench.py --gnn gat --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gat.json" 2>/dev/null
 python bench.py --gnn gatmh --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gatmh.json" 2>/dev/null
