@@ -1174,7 +1174,7 @@ int sweep_pick_r(uint32_t N, int group, uint32_t G) {
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
     double best_fill = 0;
-    for (int R : {10, 8, 6}) {
+    for (int R : {10, 8, 6, 4, 2}) {            // few rows per group: small partitions (one of 8 ranks) still fill every CU
         if (group == 16 && R == 10) continue;   // 16-lane groups stage twice the entries per lane: 10 rows would spill
         const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
         const uint32_t tiles = (rpx + RW - 1) / RW;
@@ -1232,7 +1232,8 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     } while (0)
 #define SWEEP_LAUNCH_R(GRP)                                                                                            \
     do {                                                                                                               \
-        if (R == 8) SWEEP_LAUNCH(GRP, 8); else SWEEP_LAUNCH(GRP, 6);                                                   \
+        if (R == 8) SWEEP_LAUNCH(GRP, 8); else if (R == 6) SWEEP_LAUNCH(GRP, 6); else if (R == 4) SWEEP_LAUNCH(GRP, 4);  \
+        else SWEEP_LAUNCH(GRP, 2);                                                                                     \
     } while (0)
     if (group == 32) { if (R == 10) SWEEP_LAUNCH(32, 10); else SWEEP_LAUNCH_R(32); }
     else SWEEP_LAUNCH_R(16);
