@@ -199,8 +199,21 @@ def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
     print("numpy-gnn fixture", name, "written:", os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024, "KiB")
 
 
+def gen_wire_fixture():
+    """message headers of the weight-server / Lambda protocol, bytes written by the reference's own serialisation
+    code (oracle/ref_wire.cpp includes /root/reference/src/common/utils.hpp)"""
+    exe = os.path.join(HERE, "_ref", "ref_wire")
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    import json
+    json.loads(out)
+    with open(os.path.join(GOLD, "wire_headers.json"), "w") as f:
+        f.write(out)
+    print("wire fixture written")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    gen_wire_fixture()
     gen_partition_fixtures()
     gen_numpy_gnn_fixture()
     gen_numpy_gnn_large("numpy_gnn_reddit_dims", [602, 128, 41])            # BASELINE config 2 widths

@@ -1,5 +1,5 @@
-"""CPU-only: the C-ABI library loads and exports every symbol include/dorylus_hip.h
-declares; without a GPU the product path fails loudly (no CPU fallback)."""
+"""CPU-only: the C-ABI library loads and exports every symbol include/*.h
+declare; without a GPU the product path fails loudly (no CPU fallback)."""
 import ctypes
 import os
 import re
@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(dorylus_amd.LIB_PATH):
         pytest.skip("library not built (run __graft_entry__.build())")
     lib = ctypes.CDLL(dorylus_amd.LIB_PATH)
-    for s in _declared() + _declared("dorylus_host.h"):
+    for s in _declared() + _declared("dorylus_host.h") + _declared("dorylus_wire.h"):
         assert hasattr(lib, s), s
 
 
