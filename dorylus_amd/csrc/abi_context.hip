@@ -156,6 +156,7 @@ int dory_create(int device, dory_ctx **out) {
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
     c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
+    c->opt["spmm_sweep_reserve_cus"] = 4;    // K1s under an exchange in flight: CUs per XCD its sweeps leave to the RCCL kernels
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);

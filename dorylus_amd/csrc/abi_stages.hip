@@ -128,7 +128,9 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
             SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
             if (two) {
-                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, sflags, c->scratch));
+                // under an exchange in flight the RCCL kernels need CUs of their own
+                const uint32_t reserve = c->halo_pending ? (uint32_t)c->opt["spmm_sweep_reserve_cus"] : 0u;
+                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, sflags, c->scratch, reserve));
                 if ((rc = wait_halo(c))) return rc;
                 SpmmArgs a2 = a;
                 a2.self_mode = 0;

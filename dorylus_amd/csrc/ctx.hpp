@@ -221,9 +221,10 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 int sweep_pick_r(uint32_t N, int group, uint32_t G);
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks);
-hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
+hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s,
-                             uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */);
+                             uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */,
+                             uint32_t reserve_cus = 0 /* CUs per XCD left to concurrent kernels */);
 hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
                                      hipStream_t s);
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);

@@ -1194,18 +1194,23 @@ size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nb
     // a.N stands for the number of destination positions here; the deal of build_blocked_sweep adds at most 8 * 10
     const int R = sweep_pick_r(a.N, group, G);
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
-    const uint32_t rpx = (a.N + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + G - 1) / G;
+    const uint32_t Gmin = G > 12 ? G - 8 : G;      // launches may leave up to 8 CUs per XCD to concurrent kernels
+    const uint32_t rpx = (a.N + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + Gmin - 1) / Gmin;
     const uint32_t slabs = ((a.ld >> 2) + group - 1) / group;
     return ((size_t)8 * slabs * spp * nblocks * 32 + 1) * sizeof(uint32_t);
 }
 
 // out (+)= self + (row_scale *) sum over source blocks [b_lo, b_hi); `done` = sweep_scratch_bytes() of device memory
-hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t G,
+hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, uint32_t flags,
-                             float *split_partial) {
+                             float *split_partial, uint32_t reserve) {
     if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
-    if (!sweep_supported(a, B, group) || b_hi > B.nb || G == 0 || G > 32) return hipErrorInvalidValue;
-    const int R = sweep_pick_r(B.npos, group, G);
+    if (!sweep_supported(a, B, group) || b_hi > B.nb || cus == 0 || cus > 32) return hipErrorInvalidValue;
+    const int R = sweep_pick_r(B.npos, group, cus);
+    // A sweep is the workgroups that must be resident on an XCD together; each takes a whole CU (all its registers).
+    // While other kernels hold CUs (the exchange's RCCL kernels under the local-source launch) fewer fit: a smaller
+    // sweep leaves them room -- the surplus workgroups of the next sweep simply wait at their first gates.
+    const uint32_t G = cus > 12 ? cus - std::min<uint32_t>(reserve, 8u) : cus;
     SweepArgs w{};
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
     w.rpx = ((B.npos + 7) / 8 + R - 1) / R * R;   // whole lane groups per XCD
