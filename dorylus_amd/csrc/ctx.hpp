@@ -219,6 +219,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
                                BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */);
 int sweep_pick_r(uint32_t N, int group, uint32_t G);
+void sweep_force_rows(int r);   // process-wide: rows per lane group (0 = auto)
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,

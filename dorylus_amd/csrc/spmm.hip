@@ -781,7 +781,7 @@ struct SweepArgs {
     uint32_t nsweeps;    // slabs * ceil(tiles_x / G)
     uint32_t b_lo, b_hi; // source blocks of this launch
     uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
-    uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots)
+    uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots); 8: no gates (diagnostic)
     float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
 };
 
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
             const uint32_t *word = bb >= 0 ? dq + (size_t)bb * 32
                                            : (q > 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
             const uint32_t need = bb >= 0 ? cnt_q : cnt_p;
-            if (word && (int)nbs + bb >= 0 && lane == 0) {
+            if (word && (int)nbs + bb >= 0 && lane == 0 && !(w.flags & 8u)) {   // flags bit 3: no gates (diagnostic)
                 while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sb) {
                     if (__hip_atomic_exchange(&lds_lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
                         uint32_t spins = 0;      // this wave polls for the workgroup
@@ -913,8 +913,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t rlo = ol[r], rhi = ol[r + 1];
-                if (B.seg_clamp && rhi - rlo > B.seg_clamp) rhi = rlo + B.seg_clamp;   // (not reached: hub graphs keep K1b)
+                const uint32_t rlo = ol[r], rhi = ol[r + 1];
                 const uint32_t lo = max(rlo, cs), hi = min(rhi, ce);
                 uint32_t e = lo;
                 for (; e + U <= hi; e += U) {               // full batches: nothing predicated
@@ -1170,7 +1169,11 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 }
 
 // rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab
+static int g_sweep_force_r = 0;   // option spmm_sweep_rows (tests, experiments): 0 = pick by fill
+void sweep_force_rows(int r) { g_sweep_force_r = r; }
 int sweep_pick_r(uint32_t N, int group, uint32_t G) {
+    if (g_sweep_force_r == 2 || g_sweep_force_r == 4 || g_sweep_force_r == 6 || g_sweep_force_r == 8 || (g_sweep_force_r == 10 && group == 32))
+        return g_sweep_force_r;
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
     double best_fill = 0;
