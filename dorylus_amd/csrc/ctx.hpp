@@ -48,6 +48,7 @@ struct BlockedAdj {
     uint32_t row_bytes = 0; // slab bytes per row the block size was chosen for
     uint32_t npos = 0;      // destination positions = leading dimension of boff minus 1 (N, or more with `perm`)
     uint32_t nb_local = 0;  // blocks [0, nb_local) contain local source rows only
+    uint32_t nghost = 0;    // K1s layout: ghost source rows (blocks [nb_local, nb) contain only those)
     // K1s layout (build_blocked_sweep): destination positions are a degree-balanced deal of the rows (rows of very high
     // degree cut into pieces), source rows are spread over the blocks by a random permutation (local / ghost rows apart)
     uint32_t *perm = nullptr;        // npos: position -> row, 0xFFFFFFFF = empty; nullptr = identity

@@ -785,7 +785,7 @@ struct SweepArgs {
     float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
 };
 
-template <int GROUP, int R, bool UNIT, bool GH>
+template <int GROUP, int R, bool UNIT>
 __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
                                                               SweepArgs w) {
     constexpr int GPW = 64 / GROUP;
@@ -821,7 +821,6 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const bool col_ok = col < nchunk;
     const uint32_t ccol = col_ok ? col : 0;
     const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl) + ccol;
-    const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg) + ccol;
     uint2 *st = stage[g];
     uint32_t *ol = o_lds[g];
     const uint32_t orow = min(v0 + (uint32_t)min(li, R), xend);   // lane li <= R holds the offset of row v0 + li
@@ -830,8 +829,18 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto rowp = [&](uint32_t sidx) -> const float4 * {
-        return (!GH || sidx < a.N) ? xl4 + (size_t)sidx * nchunk : xg4 + (size_t)(sidx - a.N) * nchunk;
+    // Source rows through a buffer resource: 32-bit byte offsets (row id x row bytes in one 24-bit multiply-add), and
+    // an absent slot of a tail is an out-of-range offset -- reads zeros, no memory access, no branch.  A launch covers
+    // local-source blocks or ghost blocks, never both: one base.
+    const bool ghost_launch = w.b_lo >= B.nb_local;
+    const uint32_t row_b = a.ld * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ghost_launch ? a.xg : a.xl), 0, (ghost_launch ? B.nghost : a.N) * row_b, 0x00020000);
+    const uint32_t lane_b = ccol * 16u - (ghost_launch ? a.N : 0u) * row_b;   // (mod 2^32) + idx * row_b = byte offset
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    auto gather = [&](uint32_t sidx, bool on) -> float4 {
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? __umul24(sidx, row_b) + lane_b : 0xFFFFFFFFu, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     // first pass of a step's entries: [o_0, min(o_0 + C, o_R)) of this group, one coalesced load per 32 entries
     auto load_entries = [&](uint32_t b, uint32_t my_o, uint2 (&en)[CQ]) {
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
 #pragma unroll
                     for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = *rowp(en[u].x);
+                    for (int u = 0; u < U; ++u) x[u] = gather(en[u].x, true);
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc[r] = fma4(UNIT ? 1.f : __uint_as_float(en[u].y), x[u], acc[r]);
                 }
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
                     for (int u = 0; u < U - 1; ++u) en[u] = st[min(e + u, hi - 1) - cs];
 #pragma unroll
                     for (int u = 0; u < U - 1; ++u)
-                        x[u] = (uint32_t)u < n ? *rowp(en[u].x) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        x[u] = gather(en[u].x, (uint32_t)u < n);
 #pragma unroll
                     for (int u = 0; u < U - 1; ++u)
                         acc[r] = fma4((uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f, x[u], acc[r]);
@@ -1120,6 +1129,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     B.SB = (std::max(N, G) + std::max(nbL, std::max<uint32_t>(nbG, 1)) - 1) / std::max(nbL, std::max<uint32_t>(nbG, 1));   // rows per block (nominal)
     B.npos = npos;
     B.nb_local = nbL;
+    B.nghost = G;
     B.row_bytes = row_bytes;
     uint32_t *cnt = nullptr;
     uint16_t *d_sblk = nullptr;
@@ -1189,7 +1199,11 @@ int sweep_pick_r(uint32_t N, int group, uint32_t G) {
 }
 
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
-    return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8 && B.npos >= 8;
+    // source rows are addressed through a buffer resource: 32-bit byte offsets, row id x row bytes in 24 x 24 bits
+    const uint64_t row_b = (uint64_t)a.ld * 4u;
+    const bool addr_ok = (uint64_t)a.N * row_b < (1ull << 32) && (uint64_t)B.nghost * row_b < (1ull << 32) &&
+                         (uint64_t)a.N + B.nghost < (1u << 24) && row_b < (1u << 24);
+    return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8 && B.npos >= 8 && addr_ok;
 }
 
 // counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
@@ -1209,6 +1223,8 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
                              float *split_partial, uint32_t reserve) {
     if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
     if (!sweep_supported(a, B, group) || b_hi > B.nb || cus == 0 || cus > 32) return hipErrorInvalidValue;
+    if (b_lo < B.nb_local && b_hi > B.nb_local) return hipErrorInvalidValue;   // one source array per launch
+    if (b_lo >= B.nb_local && !a.xg) return hipErrorInvalidValue;
     const int R = sweep_pick_r(B.npos, group, cus);
     // A sweep is the workgroups that must be resident on an XCD together; each takes a whole CU (all its registers).
     // While other kernels hold CUs (the exchange's RCCL kernels under the local-source launch) fewer fit: a smaller
@@ -1230,13 +1246,11 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     hipError_t e = hipMemsetAsync(done, 0, ((size_t)8 * w.nsweeps * (b_hi - b_lo) * 32 + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const dim3 gr(8u * slabs * spp * G), bl(SWEEP_NT);
-    const bool gh = a.xg != nullptr, unit = row_scale != nullptr;
+    const bool unit = row_scale != nullptr;
 #define SWEEP_LAUNCH(GRP, RR)                                                                                          \
     do {                                                                                                               \
-        if (unit) { if (gh) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true>), gr, bl, 0, s, a, B, row_scale, w);   \
-                    else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, false>), gr, bl, 0, s, a, B, row_scale, w); }   \
-        else { if (gh) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, true>), gr, bl, 0, s, a, B, row_scale, w);       \
-               else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, false>), gr, bl, 0, s, a, B, row_scale, w); }       \
+        if (unit) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true>), gr, bl, 0, s, a, B, row_scale, w);              \
+        else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false>), gr, bl, 0, s, a, B, row_scale, w);                  \
     } while (0)
 #define SWEEP_LAUNCH_R(GRP)                                                                                            \
     do {                                                                                                               \

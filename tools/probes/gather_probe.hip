@@ -87,6 +87,262 @@ static void run(const float4 *dx, uint32_t win_rows, uint32_t stride4, float4 *d
     fflush(stdout);
 }
 
+
+// K1s-shaped probe: one 1024-thread workgroup per CU, every lane group reads (row, weight) pairs from its own LDS stage
+// (filled once from an LCG), U gathers per batch, the batch summed into one of R accumulators.  SRC 0: addresses from
+// the LCG (no LDS in the chain), SRC 1: from LDS.
+template <int U, int R, int SRC>
+__global__ __launch_bounds__(1024) void k1s_probe(const float4 *__restrict__ x, uint32_t win_rows, uint32_t stride4, int iters,
+                                                  float4 *__restrict__ out) {
+    __shared__ uint2 stage[32][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, g = wave * 2 + (lane >> 5);
+    const uint32_t xcd = blockIdx.x & 7u;
+    const float4 *xw = x + (size_t)xcd * win_rows * stride4 + li;
+    uint32_t state = (blockIdx.x * 32 + g) * 2654435761u + 12345u;
+    for (int i = li; i < 128; i += 32) {
+        uint32_t st2 = state + i * 7919u;
+        st2 = st2 * 1664525u + 1013904223u;
+        stage[g][i] = make_uint2((uint32_t)(((uint64_t)(st2 >> 4) * win_rows) >> 28), 0x3f800000u);
+    }
+    __syncthreads();
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint2 *st = stage[g];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = ((it * R + r) * U) & 127 & ~(U - 1);
+            uint2 en[U];
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (SRC == 1) en[u] = st[(e + u) & 127];
+                else {
+                    state = state * 1664525u + 1013904223u;
+                    en[u] = make_uint2((uint32_t)(((uint64_t)(state >> 4) * win_rows) >> 28), 0x3f800000u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = xw[(size_t)en[u].x * stride4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = __uint_as_float(en[u].y);
+                acc[r].x += w * v[u].x; acc[r].y += w * v[u].y; acc[r].z += w * v[u].z; acc[r].w += w * v[u].w;
+            }
+        }
+    }
+    float4 t = acc[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t = add4(acc[r], t);
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = t;
+}
+
+template <int U, int R, int SRC>
+static void run_k1s(const float4 *dx, uint32_t win_rows, uint32_t stride4, float4 *dout) {
+    const int nwg = 256, iters = 4000 / (U * R);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k1s_probe<U, R, SRC>), dim3(nwg), dim3(1024), 0, 0, dx, win_rows, stride4, iters, dout);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)nwg * 1024 * iters * U * R * 16;
+    printf("k1s-shaped: 1024 threads/CU U=%d R=%2d addresses from %s: %7.3f ms  %6.2f TB/s\n", U, R, SRC ? "LDS" : "LCG", ms,
+           bytes / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+// the same with K1s's row loop: every row has n in [LO, LO + SPAN) entries (different in the two lane groups of a wave),
+// full batches of U then one predicated tail, as spmm_sweep_kernel does.  Rate counts the entries gathered.
+template <int U, int R, int LO, int SPAN>
+__global__ __launch_bounds__(1024) void k1s_rows_probe(const float4 *__restrict__ x, uint32_t win_rows, uint32_t stride4, int iters,
+                                                       float4 *__restrict__ out, unsigned long long *__restrict__ nent) {
+    __shared__ uint2 stage[32][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, g = wave * 2 + (lane >> 5);
+    const uint32_t xcd = blockIdx.x & 7u;
+    const float4 *xw = x + (size_t)xcd * win_rows * stride4 + li;
+    uint32_t state = (blockIdx.x * 32 + g) * 2654435761u + 12345u;
+    for (int i = li; i < 128; i += 32) {
+        uint32_t st2 = state + i * 7919u;
+        st2 = st2 * 1664525u + 1013904223u;
+        stage[g][i] = make_uint2((uint32_t)(((uint64_t)(st2 >> 4) * win_rows) >> 28), 0x3f800000u);
+    }
+    __syncthreads();
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint2 *st = stage[g];
+    unsigned long long cnt = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t e0 = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            state = state * 1664525u + 1013904223u;
+            const uint32_t n = LO + (state >> 8) % SPAN;
+            const uint32_t hi = e0 + n;
+            cnt += n;
+            uint32_t e = e0;
+            for (; e + U <= hi; e += U) {
+                uint2 en[U];
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) en[u] = st[(e + u) & 127];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = xw[(size_t)en[u].x * stride4];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float w = __uint_as_float(en[u].y);
+                    acc[r].x += w * v[u].x; acc[r].y += w * v[u].y; acc[r].z += w * v[u].z; acc[r].w += w * v[u].w;
+                }
+            }
+            if (e < hi) {
+                const uint32_t m = hi - e;
+                uint2 en[U - 1];
+                float4 v[U - 1];
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u) en[u] = st[(min(e + u, hi - 1)) & 127];
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u) v[u] = (uint32_t)u < m ? xw[(size_t)en[u].x * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u) {
+                    const float w = (uint32_t)u < m ? __uint_as_float(en[u].y) : 0.f;
+                    acc[r].x += w * v[u].x; acc[r].y += w * v[u].y; acc[r].z += w * v[u].z; acc[r].w += w * v[u].w;
+                }
+            }
+            e0 = hi & 127;
+        }
+    }
+    float4 t = acc[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t = add4(acc[r], t);
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = t;
+    if (li == 0) atomicAdd(nent, cnt);
+}
+
+template <int U, int R, int LO, int SPAN>
+static void run_rows(const float4 *dx, uint32_t win_rows, uint32_t stride4, float4 *dout) {
+    const int nwg = 256, iters = 4000 / (10 * R);
+    unsigned long long *dn, hn = 0;
+    CK(hipMalloc(&dn, 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(dn, 0, 8));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k1s_rows_probe<U, R, LO, SPAN>), dim3(nwg), dim3(1024), 0, 0, dx, win_rows, stride4, iters, dout, dn);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(&hn, dn, 8, hipMemcpyDeviceToHost));
+    const double bytes = (double)hn * 512;
+    printf("k1s rows: U=%d R=%2d row length %d..%d: %7.3f ms  %6.2f TB/s\n", U, R, LO, LO + SPAN - 1, ms, bytes / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+    CK(hipFree(dn));
+}
+
+// paired halves: the two 32-lane halves of a wave gather entries e and e+1 of the SAME row (one row at a time per wave,
+// R rows per wave), so the halves never run different trip counts; full batches of U instructions (2U entries), one
+// predicated tail.  Rate counts the entries gathered.
+template <int U, int R, int LO, int SPAN>
+__global__ __launch_bounds__(1024) void k1s_pair_probe(const float4 *__restrict__ x, uint32_t win_rows, uint32_t stride4, int iters,
+                                                       float4 *__restrict__ out, unsigned long long *__restrict__ nent) {
+    __shared__ uint2 stage[16][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const float4 *xw = x + (size_t)xcd * win_rows * stride4 + li;
+    uint32_t state = (blockIdx.x * 16 + wave) * 2654435761u + 12345u;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t st2 = state + i * 7919u;
+        st2 = st2 * 1664525u + 1013904223u;
+        stage[wave][i] = make_uint2((uint32_t)(((uint64_t)(st2 >> 4) * win_rows) >> 28), 0x3f800000u);
+    }
+    __syncthreads();
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint2 *st = stage[wave];
+    unsigned long long cnt = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t e0 = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            state = state * 1664525u + 1013904223u;
+            const uint32_t n = LO + (state >> 8) % SPAN;
+            const uint32_t hi = e0 + n;
+            cnt += n;
+            uint32_t e = e0;
+            for (; e + 2 * U <= hi; e += 2 * U) {
+                uint2 en[U];
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) en[u] = st[(e + 2 * u + h) & 255];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = xw[(size_t)en[u].x * stride4];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float w = __uint_as_float(en[u].y);
+                    acc[r].x += w * v[u].x; acc[r].y += w * v[u].y; acc[r].z += w * v[u].z; acc[r].w += w * v[u].w;
+                }
+            }
+            if (e < hi) {
+                uint2 en[U];
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) en[u] = st[(min(e + 2 * u + h, hi - 1)) & 255];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = e + 2 * u + h < hi ? xw[(size_t)en[u].x * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float w = e + 2 * u + h < hi ? __uint_as_float(en[u].y) : 0.f;
+                    acc[r].x += w * v[u].x; acc[r].y += w * v[u].y; acc[r].z += w * v[u].z; acc[r].w += w * v[u].w;
+                }
+            }
+            e0 = hi & 255;
+        }
+    }
+    float4 t = acc[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t = add4(acc[r], t);
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = t;
+    if (lane == 0) atomicAdd(nent, cnt);
+}
+
+template <int U, int R, int LO, int SPAN>
+static void run_pair(const float4 *dx, uint32_t win_rows, uint32_t stride4, float4 *dout) {
+    const int nwg = 256, iters = 4000 / (5 * R);
+    unsigned long long *dn, hn = 0;
+    CK(hipMalloc(&dn, 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(dn, 0, 8));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k1s_pair_probe<U, R, LO, SPAN>), dim3(nwg), dim3(1024), 0, 0, dx, win_rows, stride4, iters, dout, dn);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(&hn, dn, 8, hipMemcpyDeviceToHost));
+    const double bytes = (double)hn * 512;
+    printf("k1s paired halves: U=%d R=%2d row length %d..%d: %7.3f ms  %6.2f TB/s\n", U, R, LO, LO + SPAN - 1, ms, bytes / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+    CK(hipFree(dn));
+}
+
 int main() {
     const uint32_t stride4 = 152;                 // 608 floats per row, as x at F=602
     const size_t rows_total = 8u * 65536u;
@@ -118,6 +374,28 @@ int main() {
     printf("-- dense rows (stride = row bytes)\n");
     run<32, 8, 0>(dx, 4096, 32, dout, 8);
     run<16, 8, 0>(dx, 8192, 16, dout, 8);
+    printf("-- one 1024-thread workgroup per CU (16 waves), 512-B rows, 2 MB window\n");
+    run_k1s<4, 1, 0>(dx, 4096, stride4, dout);
+    run_k1s<4, 10, 0>(dx, 4096, stride4, dout);
+    run_k1s<4, 1, 1>(dx, 4096, stride4, dout);
+    run_k1s<4, 10, 1>(dx, 4096, stride4, dout);
+    run_k1s<8, 1, 1>(dx, 4096, stride4, dout);
+    run_k1s<8, 6, 1>(dx, 4096, stride4, dout);
+    run_k1s<2, 10, 1>(dx, 4096, stride4, dout);
+    printf("-- K1s row loop (full batches + predicated tail), row lengths differ between the two lane groups of a wave\n");
+    run_rows<4, 10, 12, 1>(dx, 4096, stride4, dout);
+    run_rows<4, 10, 10, 1>(dx, 4096, stride4, dout);
+    run_rows<4, 10, 4, 13>(dx, 4096, stride4, dout);
+    run_rows<4, 10, 1, 19>(dx, 4096, stride4, dout);
+    run_rows<2, 10, 4, 13>(dx, 4096, stride4, dout);
+    run_rows<8, 10, 4, 13>(dx, 4096, stride4, dout);
+    run_pair<4, 10, 4, 13>(dx, 4096, stride4, dout);
+    run_pair<4, 16, 4, 13>(dx, 4096, stride4, dout);
+    run_pair<4, 10, 1, 19>(dx, 4096, stride4, dout);
+    run_pair<2, 16, 4, 13>(dx, 4096, stride4, dout);
+    run_pair<3, 16, 4, 13>(dx, 4096, stride4, dout);
+    run_pair<4, 16, 8, 25>(dx, 4096, stride4, dout);
+    run_rows<4, 10, 8, 25>(dx, 4096, stride4, dout);
     printf("-- LDS-DMA gather\n");
     run<16, 4, 1>(dx, 8192, stride4, dout, 8);
     run<32, 4, 1>(dx, 4096, stride4, dout, 8);
