@@ -503,11 +503,7 @@ int dory_preallocate(dory_ctx *c) {
             if ((rc = ensure_sweep(c, false, group))) return rc;
             size_t need = 0;
             for (const BlockedAdj *S : {&c->swpIn, &c->swpOut})
-                if (S->nb) {
-                    SpmmArgs sa{};
-                    sa.N = S->npos; sa.ld = maxld;
-                    need = std::max(need, sweep_scratch_bytes(sa, group, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb));
-                }
+                if (S->nb) need = std::max(need, sweep_scratch_bytes(*S, maxld, group, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb));
             if (need > c->partial_bytes) {
                 if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;

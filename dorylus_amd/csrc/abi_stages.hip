@@ -68,7 +68,7 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd));   // the deal is made for the 32-lane launches
     HIPCK(c, build_blocked_sweep(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal, c->N,
                                  NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, window, R, &S, c->compute,
-                                 (uint32_t)c->opt["spmm_sweep_layout"]));
+                                 (uint32_t)c->opt["spmm_sweep_layout"], std::min<uint32_t>(32u, c->cus_per_xcd)));
     built = true;
     return DORY_OK;
 }
@@ -110,9 +110,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             // With ghost rows the blocks that hold local rows only always run as a launch of their own (they do not
             // depend on an exchange in flight), so the overlapped and the sequential schedule are the same arithmetic.
             const bool two = a.xg != nullptr && S.nb_local > 0 && S.nb_local < S.nb;
-            SpmmArgs sa = a;
-            sa.N = S.npos;
-            const size_t need = sweep_scratch_bytes(sa, group, G, two ? std::max(S.nb_local, S.nb - S.nb_local) : S.nb);
+            const size_t need = sweep_scratch_bytes(S, a.ld, group, G, two ? std::max(S.nb_local, S.nb - S.nb_local) : S.nb);
             if (need > c->partial_bytes) {
                 if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: sweep counters would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));

@@ -49,6 +49,7 @@ struct BlockedAdj {
     uint32_t npos = 0;      // destination positions = leading dimension of boff minus 1 (N, or more with `perm`)
     uint32_t nb_local = 0;  // blocks [0, nb_local) contain local source rows only
     uint32_t nghost = 0;    // K1s layout: ghost source rows (blocks [nb_local, nb) contain only those)
+    uint32_t rows_per_group = 0;   // K1s layout: the R its positions were dealt for
     // K1s layout (build_blocked_sweep): destination positions are a degree-balanced deal of the rows (rows of very high
     // degree cut into pieces), source rows are spread over the blocks by a random permutation (local / ghost rows apart)
     uint32_t *perm = nullptr;        // npos: position -> row, 0xFFFFFFFF = empty; nullptr = identity
@@ -218,11 +219,12 @@ void free_blocked(BlockedAdj *B);
 // K1s: the register-accumulating sweep over its own even layout of the blocked adjacency (spmm.hip)
 hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
-                               BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */);
+                               BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */,
+                               uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */);
 int sweep_pick_r(uint32_t N, int group, uint32_t G);
 void sweep_force_rows(int r);   // process-wide: rows per lane group (0 = auto)
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
-size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks);
+size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s,
                              uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */,

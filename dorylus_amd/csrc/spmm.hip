@@ -839,7 +839,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const uint32_t lane_b = ccol * 16u - (ghost_launch ? a.N : 0u) * row_b;   // (mod 2^32) + idx * row_b = byte offset
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     auto gather = [&](uint32_t sidx, bool on) -> float4 {
-        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? __umul24(sidx, row_b) + lane_b : 0xFFFFFFFFu, 0, 0);
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (on && col_ok) ? __umul24(sidx, row_b) + lane_b : 0xFFFFFFFFu, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     // first pass of a step's entries: [o_0, min(o_0 + C, o_R)) of this group, one coalesced load per 32 entries
@@ -1048,7 +1048,7 @@ constexpr uint32_t SWEEP_SPLIT = 2;
 
 hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
-                               BlockedAdj *out, hipStream_t s, uint32_t layout) {
+                               BlockedAdj *out, hipStream_t s, uint32_t layout, uint32_t sweep_tiles) {
     BlockedAdj B{};
     if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
     hipError_t e;
@@ -1080,7 +1080,42 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     const uint64_t ni64 = items.size();
     if (ni64 + 16 > 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const uint32_t nl = (uint32_t)ni64;
-    const uint32_t T = (nl + R - 1) / (uint32_t)R;              // lane groups
+    // Lane groups and their row counts.  A sweep = `sweep_tiles` workgroups of 32 lane groups per XCD that move in
+    // step, so what a sweep costs is set by the rows per group of its workgroups, and a last sweep that is only partly
+    // occupied costs as much as a full one (Reddit: 91 workgroups of 320 rows per XCD = 2.84 sweeps, paid as 3).  So the
+    // positions are laid out for whole sweeps -- 8 XCDs x S sweeps x sweep_tiles x 32 groups x R positions -- and the
+    // groups of the last sweep get fewer rows instead (their other positions stay empty): 10 + 10 + 9 rows per group
+    // instead of 3 x 10.  Groups are numbered as the kernel walks them: XCD, workgroup, group.
+    const uint32_t GS = std::max<uint32_t>(1, sweep_tiles) * 32u;      // groups per sweep and XCD
+    uint32_t T = (nl + R - 1) / (uint32_t)R;
+    std::vector<uint32_t> cap;
+    if (layout & 2u) {
+        const uint32_t n_x = (nl + 7) / 8;
+        const uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);      // rows per group, summed over the sweeps
+        const uint32_t S = (need + R - 1) / (uint32_t)R;
+        if ((uint64_t)8 * S * GS * R > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+        T = 8u * S * GS;
+        cap.assign(T, (uint32_t)R);
+        const uint32_t last = need - (S - 1) * (uint32_t)R;
+        for (uint32_t x = 0; x < 8; ++x)
+            for (uint32_t g = 0; g < GS; ++g) cap[(size_t)x * S * GS + (size_t)(S - 1) * GS + g] = last;
+        // make the capacity exact: the surplus comes off groups spread evenly over the last sweeps of all XCDs
+        uint64_t total = (uint64_t)8 * GS * need;
+        for (uint32_t sw = S; sw-- > 0 && total > nl;) {
+            const uint32_t L = 8u * GS;
+            while (total > nl) {
+                const uint64_t surplus = std::min<uint64_t>(total - nl, L);
+                bool any = false;
+                for (uint64_t k = 0; k < surplus; ++k) {
+                    const uint32_t j = (uint32_t)(k * L / surplus);          // j-th group of sweep sw, counted over the XCDs
+                    uint32_t &cg = cap[(size_t)(j / GS) * S * GS + (size_t)sw * GS + j % GS];
+                    if (cg) { --cg; --total; any = true; }
+                }
+                if (!any) break;
+            }
+        }
+        if (total != nl) return hipErrorUnknown;
+    }
     const uint32_t npos = std::max<uint32_t>(T * (uint32_t)R, 8);
     std::vector<uint32_t> perm(npos, 0xFFFFFFFFu), otgt;
     std::vector<uint2> slice;
@@ -1088,15 +1123,24 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     {
         std::vector<uint32_t> slot0(nslots ? N : 0, 0);
         for (size_t q = 0; q < split_rows.size(); q += 3) slot0[split_rows[q]] = split_rows[q + 1];
-        for (uint32_t i = 0; i < nl; ++i) {
-            const uint32_t band = i / T, j = i % T;
-            const uint32_t jj = (band & 1u) ? T - 1 - j : j;
-            const size_t pos = (layout & 2u) ? (size_t)jj * R + band : (size_t)i;
+        auto place = [&](size_t pos, uint32_t i) {
             perm[pos] = items[i].row;
             if (nslots) {
                 slice[pos] = make_uint2(items[i].k, items[i].K);
                 otgt[pos] = items[i].K > 1 ? (0x80000000u | (slot0[items[i].row] + items[i].k)) : items[i].row;
             }
+        };
+        if (layout & 2u) {
+            // bands of descending degree over the groups that still have room, alternate bands in reverse (serpentine):
+            // groups with the same number of rows carry nearly the same number of edges
+            uint32_t i = 0;
+            for (uint32_t band = 0; band < (uint32_t)R; ++band) {
+                if (!(band & 1u)) { for (uint32_t g = 0; g < T; ++g) if (cap[g] > band) place((size_t)g * R + band, i++); }
+                else { for (uint32_t g = T; g-- > 0;) if (cap[g] > band) place((size_t)g * R + band, i++); }
+            }
+            if (i != nl) return hipErrorUnknown;
+        } else {
+            for (uint32_t i = 0; i < nl; ++i) place((size_t)i, i);
         }
     }
     // source side: block of every source row
@@ -1130,6 +1174,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     B.npos = npos;
     B.nb_local = nbL;
     B.nghost = G;
+    B.rows_per_group = (uint32_t)R;
     B.row_bytes = row_bytes;
     uint32_t *cnt = nullptr;
     uint16_t *d_sblk = nullptr;
@@ -1206,14 +1251,22 @@ bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
     return (group == 16 || group == 32) && !(a.ld & 3) && B.nb > 0 && B.nchunks == 0 && a.N >= 8 && B.npos >= 8 && addr_ok;
 }
 
+// rows per lane group of a launch: what the layout was dealt for, unless forced (option) or not instantiated for the
+// lane-group width
+static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G) {
+    const int forced = sweep_pick_r(0, group, G);      // (returns the forced value whatever N when one is set)
+    if (g_sweep_force_r && forced == g_sweep_force_r) return forced;
+    if (B.rows_per_group && (group == 32 || B.rows_per_group <= 8)) return (int)B.rows_per_group;
+    return sweep_pick_r(B.npos, group, G);
+}
+
 // counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
-size_t sweep_scratch_bytes(const SpmmArgs &a, int group, uint32_t G, uint32_t nblocks) {
-    // a.N stands for the number of destination positions here; the deal of build_blocked_sweep adds at most 8 * 10
-    const int R = sweep_pick_r(a.N, group, G);
+size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks) {
+    const int R = sweep_rows_for(B, group, G);
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
     const uint32_t Gmin = G > 12 ? G - 8 : G;      // launches may leave up to 8 CUs per XCD to concurrent kernels
-    const uint32_t rpx = (a.N + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + Gmin - 1) / Gmin;
-    const uint32_t slabs = ((a.ld >> 2) + group - 1) / group;
+    const uint32_t rpx = (B.npos + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + Gmin - 1) / Gmin;
+    const uint32_t slabs = ((ld >> 2) + group - 1) / group;
     return ((size_t)8 * slabs * spp * nblocks * 32 + 1) * sizeof(uint32_t);
 }
 
@@ -1225,7 +1278,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     if (!sweep_supported(a, B, group) || b_hi > B.nb || cus == 0 || cus > 32) return hipErrorInvalidValue;
     if (b_lo < B.nb_local && b_hi > B.nb_local) return hipErrorInvalidValue;   // one source array per launch
     if (b_lo >= B.nb_local && !a.xg) return hipErrorInvalidValue;
-    const int R = sweep_pick_r(B.npos, group, cus);
+    const int R = sweep_rows_for(B, group, cus);
     // A sweep is the workgroups that must be resident on an XCD together; each takes a whole CU (all its registers).
     // While other kernels hold CUs (the exchange's RCCL kernels under the local-source launch) fewer fit: a smaller
     // sweep leaves them room -- the surplus workgroups of the next sweep simply wait at their first gates.
