@@ -222,6 +222,9 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
                                BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */,
                                uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */);
 int sweep_pick_r(uint32_t N, int group, uint32_t G);
+// host/sweep_deal.cpp: rows per lane group of the K1s layout and the position of every (sorted) item
+bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos);
+bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);
 void sweep_force_rows(int r);   // process-wide: rows per lane group (0 = auto)
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks);

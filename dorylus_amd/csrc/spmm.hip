@@ -1080,67 +1080,30 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     const uint64_t ni64 = items.size();
     if (ni64 + 16 > 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const uint32_t nl = (uint32_t)ni64;
-    // Lane groups and their row counts.  A sweep = `sweep_tiles` workgroups of 32 lane groups per XCD that move in
-    // step, so what a sweep costs is set by the rows per group of its workgroups, and a last sweep that is only partly
-    // occupied costs as much as a full one (Reddit: 91 workgroups of 320 rows per XCD = 2.84 sweeps, paid as 3).  So the
-    // positions are laid out for whole sweeps -- 8 XCDs x S sweeps x sweep_tiles x 32 groups x R positions -- and the
-    // groups of the last sweep get fewer rows instead (their other positions stay empty): 10 + 10 + 9 rows per group
-    // instead of 3 x 10.  Groups are numbered as the kernel walks them: XCD, workgroup, group.
-    const uint32_t GS = std::max<uint32_t>(1, sweep_tiles) * 32u;      // groups per sweep and XCD
-    uint32_t T = (nl + R - 1) / (uint32_t)R;
-    std::vector<uint32_t> cap;
+    // lane groups and their row counts, position of every item: host/sweep_deal.cpp (whole sweeps, the last sweep's
+    // groups carry fewer rows; bands of descending degree, serpentine)
+    uint32_t npos = std::max<uint32_t>((nl + R - 1) / (uint32_t)R * (uint32_t)R, 8);
+    std::vector<uint32_t> ipos(nl);
     if (layout & 2u) {
-        const uint32_t n_x = (nl + 7) / 8;
-        const uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);      // rows per group, summed over the sweeps
-        const uint32_t S = (need + R - 1) / (uint32_t)R;
-        if ((uint64_t)8 * S * GS * R > 0xFFFFFFF0ull) return hipErrorInvalidValue;
-        T = 8u * S * GS;
-        cap.assign(T, (uint32_t)R);
-        const uint32_t last = need - (S - 1) * (uint32_t)R;
-        for (uint32_t x = 0; x < 8; ++x)
-            for (uint32_t g = 0; g < GS; ++g) cap[(size_t)x * S * GS + (size_t)(S - 1) * GS + g] = last;
-        // make the capacity exact: the surplus comes off groups spread evenly over the last sweeps of all XCDs
-        uint64_t total = (uint64_t)8 * GS * need;
-        for (uint32_t sw = S; sw-- > 0 && total > nl;) {
-            const uint32_t L = 8u * GS;
-            while (total > nl) {
-                const uint64_t surplus = std::min<uint64_t>(total - nl, L);
-                bool any = false;
-                for (uint64_t k = 0; k < surplus; ++k) {
-                    const uint32_t j = (uint32_t)(k * L / surplus);          // j-th group of sweep sw, counted over the XCDs
-                    uint32_t &cg = cap[(size_t)(j / GS) * S * GS + (size_t)sw * GS + j % GS];
-                    if (cg) { --cg; --total; any = true; }
-                }
-                if (!any) break;
-            }
-        }
-        if (total != nl) return hipErrorUnknown;
+        std::vector<uint32_t> cap;
+        if (!sweep_deal_plan(nl, (uint32_t)R, sweep_tiles, &cap, &npos) || !sweep_deal_positions(nl, (uint32_t)R, cap, ipos.data()))
+            return hipErrorInvalidValue;
+    } else {
+        for (uint32_t i = 0; i < nl; ++i) ipos[i] = i;
     }
-    const uint32_t npos = std::max<uint32_t>(T * (uint32_t)R, 8);
     std::vector<uint32_t> perm(npos, 0xFFFFFFFFu), otgt;
     std::vector<uint2> slice;
     if (nslots) { otgt.assign(npos, 0xFFFFFFFFu); slice.assign(npos, make_uint2(0u, 1u)); }
     {
         std::vector<uint32_t> slot0(nslots ? N : 0, 0);
         for (size_t q = 0; q < split_rows.size(); q += 3) slot0[split_rows[q]] = split_rows[q + 1];
-        auto place = [&](size_t pos, uint32_t i) {
+        for (uint32_t i = 0; i < nl; ++i) {
+            const size_t pos = ipos[i];
             perm[pos] = items[i].row;
             if (nslots) {
                 slice[pos] = make_uint2(items[i].k, items[i].K);
                 otgt[pos] = items[i].K > 1 ? (0x80000000u | (slot0[items[i].row] + items[i].k)) : items[i].row;
             }
-        };
-        if (layout & 2u) {
-            // bands of descending degree over the groups that still have room, alternate bands in reverse (serpentine):
-            // groups with the same number of rows carry nearly the same number of edges
-            uint32_t i = 0;
-            for (uint32_t band = 0; band < (uint32_t)R; ++band) {
-                if (!(band & 1u)) { for (uint32_t g = 0; g < T; ++g) if (cap[g] > band) place((size_t)g * R + band, i++); }
-                else { for (uint32_t g = T; g-- > 0;) if (cap[g] > band) place((size_t)g * R + band, i++); }
-            }
-            if (i != nl) return hipErrorUnknown;
-        } else {
-            for (uint32_t i = 0; i < nl; ++i) place((size_t)i, i);
         }
     }
     // source side: block of every source row

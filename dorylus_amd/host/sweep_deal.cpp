@@ -1,0 +1,75 @@
+// sweep_deal.cpp -- the destination side of the K1s layout (csrc/spmm.hip: build_blocked_sweep): which position each
+// row (or piece of a split row) takes.  Pure host code so that it can be tested without a GPU (dory_sweep_deal).
+//
+// A sweep = `sweep_tiles` workgroups of 32 lane groups per XCD that move in step, so what a sweep costs is set by the
+// rows per group of its workgroups, and a last sweep that is only partly occupied costs as much as a full one (Reddit:
+// 91 workgroups of 320 rows per XCD = 2.84 sweeps, paid as 3).  The positions are therefore laid out for whole sweeps --
+// 8 XCDs x S sweeps x sweep_tiles x 32 groups x R positions -- and the groups of the last sweep get fewer rows instead
+// (their other positions stay empty): 10 + 10 + 9 rows per group instead of 3 x 10.  Groups are numbered as the kernel
+// walks them: XCD, workgroup, group.  Items arrive sorted by descending weight (edges) and are dealt in bands over the
+// groups that still have room, alternate bands in reverse (serpentine), so that groups with the same number of rows
+// carry nearly the same number of edges.
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/dorylus_host.h"
+
+namespace dory {
+
+// returns false on overflow; cap[g] = rows of group g, npos = T * R
+bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos) {
+    if (R == 0) return false;
+    const uint32_t GS = std::max<uint32_t>(1, sweep_tiles) * 32u;      // groups per sweep and XCD
+    const uint32_t n_x = (nl + 7) / 8;
+    const uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);  // rows per group, summed over the sweeps
+    const uint32_t S = (need + R - 1) / R;
+    if ((uint64_t)8 * S * GS * R > 0xFFFFFFF0ull) return false;
+    const uint32_t T = 8u * S * GS;
+    cap->assign(T, R);
+    const uint32_t last = need - (S - 1) * R;
+    for (uint32_t x = 0; x < 8; ++x)
+        for (uint32_t g = 0; g < GS; ++g) (*cap)[(size_t)x * S * GS + (size_t)(S - 1) * GS + g] = last;
+    // make the capacity exact: the surplus comes off groups spread evenly over the last sweeps of all XCDs
+    uint64_t total = (uint64_t)8 * GS * need;
+    const uint32_t L = 8u * GS;
+    for (uint32_t sw = S; sw-- > 0 && total > nl;) {
+        while (total > nl) {
+            const uint64_t surplus = std::min<uint64_t>(total - nl, L);
+            bool any = false;
+            for (uint64_t k = 0; k < surplus; ++k) {
+                const uint32_t j = (uint32_t)(k * L / surplus);          // j-th group of sweep sw, counted over the XCDs
+                uint32_t &cg = (*cap)[(size_t)(j / GS) * S * GS + (size_t)sw * GS + j % GS];
+                if (cg) { --cg; --total; any = true; }
+            }
+            if (!any) break;
+        }
+    }
+    if (total != nl) return false;
+    *npos = std::max<uint32_t>(T * R, 8);
+    return true;
+}
+
+// pos[i] = position of item i (items sorted by descending weight)
+bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos) {
+    const uint32_t T = (uint32_t)cap.size();
+    uint32_t i = 0;
+    for (uint32_t band = 0; band < R; ++band) {
+        if (!(band & 1u)) { for (uint32_t g = 0; g < T; ++g) if (cap[g] > band) { if (i >= nl) return false; pos[i++] = g * R + band; } }
+        else { for (uint32_t g = T; g-- > 0;) if (cap[g] > band) { if (i >= nl) return false; pos[i++] = g * R + band; } }
+    }
+    return i == nl;
+}
+
+}  // namespace dory
+
+extern "C" int dory_sweep_deal(uint32_t items, uint32_t rows_per_group, uint32_t sweep_tiles, uint32_t *positions_out,
+                               uint32_t *group_rows_out, uint32_t *item_position) {
+    std::vector<uint32_t> cap;
+    uint32_t npos = 0;
+    if (!dory::sweep_deal_plan(items, rows_per_group, sweep_tiles, &cap, &npos)) return 1;
+    if (positions_out) *positions_out = npos;
+    if (group_rows_out) std::copy(cap.begin(), cap.end(), group_rows_out);
+    if (item_position && !dory::sweep_deal_positions(items, rows_per_group, cap, item_position)) return 2;
+    return 0;
+}

@@ -112,6 +112,14 @@ int dory_engine_trace_epoch(int gnn_type, uint32_t num_layers, char *buf, size_t
 /* "<EM>: ..." style report of the last run into buf (engine/utils.cpp:219-291) */
 int dory_engine_report(dory_engine *e, char *buf, size_t buflen);
 
+/* Layout introspection (tests): the destination side of the K1s layout -- dorylus_amd/host/sweep_deal.cpp.  `items` rows
+ * (sorted by descending edge count) are dealt over 8 XCDs x S sweeps x sweep_tiles workgroups x 32 lane groups x
+ * rows_per_group positions; groups of the last sweep carry fewer rows so that every sweep is whole.  positions_out: total
+ * positions; group_rows_out (positions / rows_per_group entries, may be NULL): rows of every group; item_position
+ * (`items` entries, may be NULL): the position of item i.  0 = ok. */
+int dory_sweep_deal(uint32_t items, uint32_t rows_per_group, uint32_t sweep_tiles, uint32_t *positions_out,
+                    uint32_t *group_rows_out, uint32_t *item_position);
+
 #ifdef __cplusplus
 }
 #endif
