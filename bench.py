@@ -271,7 +271,7 @@ def main():
     avg_launch_ms = spmm_ms / max(spmm_n, 1)
     achieved = (algo / launches_per_epoch) / (avg_launch_ms * 1e-3) / 1e9   # GB/s per average launch
     variant = ctx.get_option("spmm_variant")
-    kernel_name = {2: "spmm_sweep_kernel<32,R,false> (K1s: register accumulators, gated per-XCD sweep over the source blocks; one aggregate = one launch)",
+    kernel_name = {2: "spmm_sweep_kernel<32,R,false,PAIR> (K1s: register accumulators, gated per-XCD sweep over the source blocks; one aggregate = one launch)",
                    1: "spmm_blocked_kernel<32> + spmm_reduce_kernel (K1b; one aggregate = both)",
                    0: "spmm_rows_kernel<64,3> / <32,1> (K1 row gather)"}.get(variant, "spmm")
     traffic = None   # HBM-side bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)

@@ -156,7 +156,8 @@ int dory_create(int device, dory_ctx **out) {
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
     c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
-    c->opt["spmm_sweep_rows"] = 0;           // K1s: rows per lane group, 0 = by fill (2/4/6/8/10; process-wide, for tests and experiments)
+    c->opt["spmm_sweep_rows"] = 0;
+    c->opt["spmm_sweep_pair"] = -1;          // K1s: two rows of a lane group as one stream of entries: -1 = launches of >= 3 slabs, 0 = never, 1 = always           // K1s: rows per lane group, 0 = by fill (2/4/6/8/10; process-wide, for tests and experiments)
     c->opt["spmm_sweep_reserve_cus"] = 4;    // K1s under an exchange in flight: CUs per XCD its sweeps leave to the RCCL kernels
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
@@ -738,6 +739,7 @@ int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
     if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
     c->opt[key] = value;
     if (!strcmp(key, "spmm_sweep_rows")) sweep_force_rows((int)value);   // process-wide (a test / experiment knob)
+    if (!strcmp(key, "spmm_sweep_pair")) sweep_force_pair((int)value);   // likewise: -1 = by the number of slabs, 0 / 1
     return DORY_OK;
 }
 

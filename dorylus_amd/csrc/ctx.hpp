@@ -226,6 +226,7 @@ int sweep_pick_r(uint32_t N, int group, uint32_t G);
 bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos);
 bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);
 void sweep_force_rows(int r);   // process-wide: rows per lane group (0 = auto)
+void sweep_force_pair(int p);   // process-wide: rows in pairs (-1 = by the number of slabs)
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,

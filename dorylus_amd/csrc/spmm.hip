@@ -785,7 +785,7 @@ struct SweepArgs {
     float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
 };
 
-template <int GROUP, int R, bool UNIT>
+template <int GROUP, int R, bool UNIT, bool PAIR>
 __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
                                                               SweepArgs w) {
     constexpr int GPW = 64 / GROUP;
@@ -920,6 +920,48 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
                     }
                 }
             }
+            if constexpr (PAIR) {
+            // two consecutive rows of a lane group as one stream of entries: one tail per two rows, and the two lane
+            // groups of a wave differ less over 20 entries than over 10; an entry goes to the first or the second row's
+            // accumulator by its place (both products are formed, one with weight 0)
+#pragma unroll
+            for (int rr = 0; rr < R / 2; ++rr) {
+                const uint32_t o0 = ol[2 * rr], o1 = ol[2 * rr + 1], o2 = ol[2 * rr + 2];
+                const uint32_t lo = max(o0, cs), hi = min(o2, ce), mid = o1;
+                uint32_t e = lo;
+                for (; e + U <= hi; e += U) {
+                    uint2 en[U];
+                    float4 x[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x[u] = gather(en[u].x, true);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float wv = UNIT ? 1.f : __uint_as_float(en[u].y);
+                        const bool first = e + u < mid;
+                        acc[2 * rr] = fma4(first ? wv : 0.f, x[u], acc[2 * rr]);
+                        acc[2 * rr + 1] = fma4(first ? 0.f : wv, x[u], acc[2 * rr + 1]);
+                    }
+                }
+                if (e < hi) {
+                    const uint32_t n = hi - e;
+                    uint2 en[U - 1];
+                    float4 x[U - 1];
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) en[u] = st[min(e + u, hi - 1) - cs];
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) x[u] = gather(en[u].x, (uint32_t)u < n);
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) {
+                        const float wv = (uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f;
+                        const bool first = e + u < mid;
+                        acc[2 * rr] = fma4(first ? wv : 0.f, x[u], acc[2 * rr]);
+                        acc[2 * rr + 1] = fma4(first ? 0.f : wv, x[u], acc[2 * rr + 1]);
+                    }
+                }
+            }
+            } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t rlo = ol[r], rhi = ol[r + 1];
@@ -948,6 +990,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
                     for (int u = 0; u < U - 1; ++u)
                         acc[r] = fma4((uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f, x[u], acc[r]);
                 }
+            }
             }
         }
         // first pass of the next step's entries: in flight across the gate
@@ -1189,6 +1232,8 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 // rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab
 static int g_sweep_force_r = 0;   // option spmm_sweep_rows (tests, experiments): 0 = pick by fill
 void sweep_force_rows(int r) { g_sweep_force_r = r; }
+static int g_sweep_pair = -1;     // option spmm_sweep_pair
+void sweep_force_pair(int p) { g_sweep_pair = p; }
 int sweep_pick_r(uint32_t N, int group, uint32_t G) {
     if (g_sweep_force_r == 2 || g_sweep_force_r == 4 || g_sweep_force_r == 6 || g_sweep_force_r == 8 || (g_sweep_force_r == 10 && group == 32))
         return g_sweep_force_r;
@@ -1263,10 +1308,16 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     if (e != hipSuccess) return e;
     const dim3 gr(8u * slabs * spp * G), bl(SWEEP_NT);
     const bool unit = row_scale != nullptr;
+    // rows in pairs (one stream of entries per two rows) pay on launches of several slabs (five slabs, F=602: 13.8 ->
+    // 13.3 ms; four: 11.0 -> 10.8; three: 8.16 -> 8.1), not on one or two (F=128: 2.70 -> 2.78; F=256: 5.43 -> 5.46);
+    // g_sweep_pair: -1 = that rule, 0 / 1 = forced (experiments)
+    const bool pair = g_sweep_pair < 0 ? slabs >= 3 : g_sweep_pair != 0;
 #define SWEEP_LAUNCH(GRP, RR)                                                                                          \
     do {                                                                                                               \
-        if (unit) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true>), gr, bl, 0, s, a, B, row_scale, w);              \
-        else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false>), gr, bl, 0, s, a, B, row_scale, w);                  \
+        if (unit) { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true>), gr, bl, 0, s, a, B, row_scale, w);   \
+                    else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, false>), gr, bl, 0, s, a, B, row_scale, w); }   \
+        else { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, true>), gr, bl, 0, s, a, B, row_scale, w);       \
+               else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, false>), gr, bl, 0, s, a, B, row_scale, w); }       \
     } while (0)
 #define SWEEP_LAUNCH_R(GRP)                                                                                            \
     do {                                                                                                               \
