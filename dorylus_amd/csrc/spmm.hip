@@ -1035,17 +1035,30 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     }
 }
 
-// out[row] (+)= self + (row_scale *) sum of the row's pieces, in piece order (one workgroup per split row)
-__global__ __launch_bounds__(256) void spmm_sweep_combine_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
-                                                                 const float *split_partial) {
+// out[row] (+)= self + (row_scale *) sum of the row's pieces, in piece order.  TPR threads per split row (a float4
+// column each), several rows per workgroup on narrow tensors; eight pieces are requested at a time so that the loads of
+// a hub row's hundreds of pieces overlap -- the adds stay in piece order.
+__global__ __launch_bounds__(320) void spmm_sweep_combine_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
+                                                                 const float *split_partial, uint32_t tpr) {
     const uint32_t nchunk = a.ld >> 2;
-    const uint32_t v = B.split_rows[3 * blockIdx.x], s0 = B.split_rows[3 * blockIdx.x + 1], K = B.split_rows[3 * blockIdx.x + 2];
+    const uint32_t rpb = blockDim.x / tpr;
+    const uint32_t sr = blockIdx.x * rpb + threadIdx.x / tpr;
+    if (sr >= B.nsplit) return;
+    const uint32_t v = B.split_rows[3 * sr], s0 = B.split_rows[3 * sr + 1], K = B.split_rows[3 * sr + 2];
     const float4 *p4 = reinterpret_cast<const float4 *>(split_partial) + (size_t)s0 * nchunk;
     const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
     float4 *out4 = reinterpret_cast<float4 *>(a.out) + (size_t)v * nchunk;
-    for (uint32_t col = threadIdx.x; col < nchunk; col += 256) {
+    for (uint32_t col = threadIdx.x % tpr; col < nchunk; col += tpr) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t k = 0; k < K; ++k) {
+        uint32_t k = 0;
+        for (; k + 8 <= K; k += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p4[(size_t)(k + u) * nchunk + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+        }
+        for (; k < K; ++k) {
             const float4 t = p4[(size_t)k * nchunk + col];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
@@ -1068,7 +1081,11 @@ __global__ __launch_bounds__(256) void spmm_sweep_combine_kernel(SpmmArgs a, Blo
 hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
                                      hipStream_t s) {
     if (!B.nsplit || a.ld == 0) return hipSuccess;
-    hipLaunchKernelGGL(spmm_sweep_combine_kernel, dim3(B.nsplit), dim3(256), 0, s, a, B, row_scale, split_partial);
+    const uint32_t nchunk = a.ld >> 2;
+    const uint32_t tpr = std::min<uint32_t>(256u, (nchunk + 31u) & ~31u);      // threads per row: whole half-waves
+    const uint32_t rpb = std::max<uint32_t>(1u, 320u / tpr);
+    hipLaunchKernelGGL(spmm_sweep_combine_kernel, dim3((B.nsplit + rpb - 1) / rpb), dim3(tpr * rpb), 0, s, a, B, row_scale,
+                       split_partial, tpr);
     return hipGetLastError();
 }
 
