@@ -165,6 +165,20 @@ def test_sweep_variant_several_sweeps_and_unit_weights(da):
             outs[(variant, nb)] = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
             assert rel_err(outs[(variant, nb)][0], ref_f) < 1e-5, (F, variant, nb)
             assert rel_err(outs[(variant, nb)][1], ref_b) < 1e-5, (F, variant, nb)
+        # two rows of a lane group as one stream of entries (the default from three slabs on) and the plain row loop,
+        # forced either way at both widths: the additions inside a row keep their order -> the same bits
+        ctx.set_option("spmm_variant", 2)
+        base = None
+        for pair in (-1, 0, 1):
+            ctx.set_option("spmm_sweep_pair", pair)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            got = (ctx.download(0, "ah"), ctx.download(0, "aTg"))
+            if base is None:
+                base = got
+                assert rel_err(got[0], ref_f) < 1e-5 and rel_err(got[1], ref_b) < 1e-5
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), (F, pair)
+        ctx.set_option("spmm_sweep_pair", -1)
         ctx.close()
     # reference GAT prototype, whole epoch: unit-weight sweep with row factors (default) vs general K1
     res = {}
