@@ -874,3 +874,45 @@ def test_rccl_communicator_inside_the_library(da):
     assert np.isfinite(ctx.weight_get(0, "w")).all()
     eng.close()
     ctx.close()
+
+
+def test_sweep_variant_random_shapes(da):
+    """K1s against the oracle on a spread of shapes the fixed cases do not hit: vertex counts around the layout's group
+    and sweep boundaries, empty and very long rows (pieces), odd widths, explicit and automatic block counts, forced rows
+    per lane group (process-wide option, restored) -- forward (CSC) and backward (CSR) on every one."""
+    import orc
+    import partition_oracle as po
+    from helpers import make_ctx, rel_err
+    rng = np.random.default_rng(2026)
+    cases = [  # V, E, F, nb, rows, skew
+        (9, 40, 32, 8, 0, 0), (65, 900, 96, 8, 2, 0), (1023, 9000, 64, 16, 0, 0), (1025, 30000, 128, 8, 4, 1),
+        (8193, 100000, 41, 24, 0, 0), (8200, 160000, 300, 16, 8, 2), (20000, 400000, 256, 0, 0, 0),
+        (33000, 700000, 132, 40, 6, 1), (70001, 1500000, 64, 0, 10, 2), (120000, 2000000, 602, 0, 0, 1),
+    ]
+    try:
+        for V, E, F, nb, rows, skew in cases:
+            if skew == 0:
+                s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+            elif skew == 1:   # a few hubs: rows far above twice the mean degree (cut into pieces), many empty rows
+                d = np.where(rng.random(E) < 0.3, rng.integers(0, max(1, V // 500), E), rng.integers(0, V // 2 + 1, E))
+                s = rng.integers(0, V, E)
+            else:             # power law on both sides
+                s = (V * rng.random(E) ** 3).astype(np.int64) % V
+                d = (V * rng.random(E) ** 3).astype(np.int64) % V
+            g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+            ctx = make_ctx(da, g, [F, F, 3], V, options={"spmm_variant": 2, "spmm_blk_nb": nb, "spmm_sweep_rows": rows})
+            x = rng.standard_normal((V, F)).astype(np.float32)
+            gr = rng.standard_normal((V, F)).astype(np.float32)
+            ctx.upload(0, "x", x)
+            ctx.upload(1, "grad", gr)
+            ctx.aggregate(0, da.FORWARD)
+            ctx.aggregate(1, da.BACKWARD)
+            ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
+            ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr)
+            assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (V, E, F, nb, rows, skew)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (V, E, F, nb, rows, skew)
+            ctx.close()
+    finally:
+        c = da.Context(0)
+        c.set_option("spmm_sweep_rows", 0)
+        c.close()
