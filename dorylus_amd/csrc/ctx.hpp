@@ -60,6 +60,7 @@ struct BlockedAdj {
     uint32_t *boff = nullptr;   // [nb][N+1]: row offsets inside the block
     uint32_t *bidx = nullptr;   // nnz: source row (virtual id), block-major / row-minor / edge order
     float *bval = nullptr;      // nnz
+    uint2 *bent = nullptr;      // K1s layout: (bidx, bval bits) interleaved instead of the two arrays (nnz + 2 entries, 16-byte aligned pairs)
     // (block,row) segments longer than BLK_SEG_CLAMP edges (hubs): K1b stops there, the remainder is cut into chunks
     // of BLK_SEG_CHUNK edges for workgroup-per-chunk kernels (spmm.hip); all empty on graphs without such segments
     uint32_t seg_clamp = 0;             // 0: no long segments

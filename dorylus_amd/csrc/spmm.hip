@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, 
                                                        const uint64_t *bbase, const uint32_t *boff,
                                                        uint32_t *cursor /*[nb][N] scratch*/, uint32_t *bidx,
                                                        float *bval, const uint32_t *perm, const uint16_t *sblk,
-                                                       const uint2 *slice) {
+                                                       const uint2 *slice, uint2 *bent = nullptr) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const uint32_t v = perm ? perm[p] : p;
@@ -378,8 +378,12 @@ __global__ __launch_bounds__(256) void blk_fill_kernel(uint32_t N, uint32_t nb, 
         const uint32_t s = idx[e];
         const uint32_t b = sblk ? (uint32_t)sblk[s] : s / SB;
         const uint64_t pos = bbase[b] + cursor[(size_t)b * N + p]++;
-        bidx[pos] = s;
-        bval[pos] = val[e];
+        if (bent) {
+            bent[pos] = make_uint2(s, __float_as_uint(val[e]));
+        } else {
+            bidx[pos] = s;
+            bval[pos] = val[e];
+        }
     }
 }
 
@@ -476,6 +480,7 @@ void free_blocked(BlockedAdj *B) {
     if (B->bbase) (void)hipFree(B->bbase);
     if (B->bidx) (void)hipFree(B->bidx);
     if (B->bval) (void)hipFree(B->bval);
+    if (B->bent) (void)hipFree(B->bent);
     for (uint32_t *q : {B->seg_row, B->seg_blk, B->seg_chunk_ptr, B->seg_chunks, B->perm, B->otgt, B->split_rows})
         if (q) (void)hipFree(q);
     *B = BlockedAdj{};
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     constexpr int NGRP = SWEEP_NT / GROUP;
     constexpr int NW = SWEEP_NT / 64;
     constexpr int RW = NGRP * R;
-    constexpr int C = SWEEP_C, U = SWEEP_U, CQ = C / GROUP;
+    constexpr int C = SWEEP_C, U = SWEEP_U, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
     __shared__ uint2 stage[NGRP][C];
     __shared__ uint32_t o_lds[NGRP][R + 2];
     __shared__ uint32_t lds_allowed, lds_lock, lds_cnt[8];
@@ -842,24 +847,31 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (on && col_ok) ? __umul24(sidx, row_b) + lane_b : 0xFFFFFFFFu, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
-    // first pass of a step's entries: [o_0, min(o_0 + C, o_R)) of this group, one coalesced load per 32 entries
-    auto load_entries = [&](uint32_t b, uint32_t my_o, uint2 (&en)[CQ]) {
-        const uint64_t base = B.bbase[b];
-        const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
+    // a pass of a step's entries: [cs, min(cs + CE, o_R)) of this group.  (idx, val) pairs are interleaved in the blocked
+    // copy and travel two per lane and load (the addresser spends as long on a 4-byte load as on a 16-byte one); the
+    // pair that holds the pass's first entry may begin one entry early
+    auto load_entries = [&](uint64_t base, uint32_t cs, uint32_t oR, u4 (&en)[CQ]) {
+        const uint64_t A0 = (base + cs) & ~1ull, Aend = base + oR;
 #pragma unroll
         for (int qq = 0; qq < CQ; ++qq) {
-            const uint32_t p = o0 + qq * GROUP + li;
-            en[qq] = make_uint2(0u, 0u);
-            if (p < oR) {
-                en[qq].x = __builtin_nontemporal_load(B.bidx + base + p);
-                if constexpr (!UNIT) en[qq].y = __float_as_uint(__builtin_nontemporal_load(B.bval + base + p));
-            }
+            const uint64_t aa = A0 + 2u * (uint32_t)(qq * GROUP + li);
+            en[qq] = (u4){0u, 0u, 0u, 0u};
+            if (aa < Aend) en[qq] = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(B.bent) + (aa >> 1));
+        }
+    };
+    auto stage_entries = [&](uint64_t base, uint32_t cs, uint32_t ce, const u4 (&en)[CQ]) {
+        const int p0 = (int)(((base + cs) & ~1ull) - base) - (int)cs;      // 0 or -1: stage index of the first loaded entry
+#pragma unroll
+        for (int qq = 0; qq < CQ; ++qq) {
+            const int i0 = p0 + 2 * (qq * GROUP + li);
+            if (i0 >= 0 && (uint32_t)i0 < ce - cs) st[i0] = make_uint2(en[qq].x, en[qq].y);
+            if (i0 + 1 >= 0 && (uint32_t)(i0 + 1) < ce - cs) st[i0 + 1] = make_uint2(en[qq].z, en[qq].w);
         }
     };
 
     uint32_t my_o = (B.boff + (size_t)w.b_lo * (B.npos + 1))[orow];
-    uint2 en_pre[CQ];
-    load_entries(w.b_lo, my_o, en_pre);
+    u4 en_pre[CQ];
+    load_entries(B.bbase[w.b_lo], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
 
     for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
         const uint32_t sb = b - w.b_lo;                      // step of this launch
@@ -903,23 +915,10 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         if (li <= R) ol[li] = my_o;
         const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
         const uint64_t base = B.bbase[b];
-        for (uint32_t cs = o0; cs < oR; cs += C) {
-            const uint32_t ce = min(cs + C, oR);
-            if (cs == o0) {
-#pragma unroll
-                for (int qq = 0; qq < CQ; ++qq)
-                    if (cs + qq * GROUP + li < ce) st[qq * GROUP + li] = en_pre[qq];
-            } else {
-#pragma unroll
-                for (int qq = 0; qq < CQ; ++qq) {
-                    const uint32_t p = cs + qq * GROUP + li;
-                    if (p < ce) {
-                        uint2 en = make_uint2(__builtin_nontemporal_load(B.bidx + base + p), 0u);
-                        if constexpr (!UNIT) en.y = __float_as_uint(__builtin_nontemporal_load(B.bval + base + p));
-                        st[qq * GROUP + li] = en;
-                    }
-                }
-            }
+        for (uint32_t cs = o0; cs < oR; cs += CE) {
+            const uint32_t ce = min(cs + CE, oR);
+            if (cs != o0) load_entries(base, cs, oR, en_pre);      // (rare: more than CE entries of the group in one step)
+            stage_entries(base, cs, ce, en_pre);
             if constexpr (PAIR) {
             // two consecutive rows of a lane group as one stream of entries: one tail per two rows, and the two lane
             // groups of a wave differ less over 20 entries than over 10; an entry goes to the first or the second row's
@@ -995,7 +994,8 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         }
         // first pass of the next step's entries: in flight across the gate
         my_o = my_o_next;
-        if (b + 1 < w.b_hi) load_entries(b + 1, my_o, en_pre);
+        if (b + 1 < w.b_hi)
+            load_entries(B.bbase[b + 1], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
         if (lane == 0) {   // the last wave to finish the step reports it for the workgroup
             const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == NW - 1) {
@@ -1221,8 +1221,8 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     BCK(hipMemsetAsync(cnt, 0, (size_t)nb * npos * sizeof(uint32_t), s));
     BCK(hipMalloc((void **)&B.boff, (size_t)nb * (npos + 1) * sizeof(uint32_t)));
     BCK(hipMalloc((void **)&B.bbase, (size_t)(nb + 1) * sizeof(uint64_t)));
-    BCK(hipMalloc((void **)&B.bidx, (nnz ? nnz : 1) * sizeof(uint32_t)));
-    BCK(hipMalloc((void **)&B.bval, (nnz ? nnz : 1) * sizeof(float)));
+    BCK(hipMalloc((void **)&B.bent, (nnz + 2) * sizeof(uint2)));
+    BCK(hipMemsetAsync(B.bent + nnz, 0, 2 * sizeof(uint2), s));
     BCK(hipMalloc((void **)&dtotal, nb * sizeof(uint64_t)));
     hipLaunchKernelGGL(blk_count_kernel, dim3((npos + 255) / 256), dim3(256), 0, s, npos, ptr, idx, B.SB, cnt, B.perm, d_sblk,
                        (const uint2 *)d_slice);
@@ -1234,7 +1234,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     if (base[nb] != nnz) return hipErrorUnknown;
     BCK(hipMemcpyAsync(B.bbase, base.data(), (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(blk_fill_kernel, dim3((npos + 255) / 256), dim3(256), 0, s, npos, nb, ptr, idx, val, B.SB, B.bbase,
-                       B.boff, cnt, B.bidx, B.bval, B.perm, d_sblk, (const uint2 *)d_slice);
+                       B.boff, cnt, (uint32_t *)nullptr, (float *)nullptr, B.perm, d_sblk, (const uint2 *)d_slice, B.bent);
     BCK(hipGetLastError());
     BCK(hipStreamSynchronize(s));
     (void)hipFree(cnt);
