@@ -888,6 +888,8 @@ def test_sweep_variant_random_shapes(da):
         (9, 40, 32, 8, 0, 0), (65, 900, 96, 8, 2, 0), (1023, 9000, 64, 16, 0, 0), (1025, 30000, 128, 8, 4, 1),
         (8193, 100000, 41, 24, 0, 0), (8200, 160000, 300, 16, 8, 2), (20000, 400000, 256, 0, 0, 0),
         (33000, 700000, 132, 40, 6, 1), (70001, 1500000, 64, 0, 10, 2), (120000, 2000000, 602, 0, 0, 1),
+        # dense: a lane group's entries of one step exceed a staging pass (127), with rows in pairs (3 slabs) and without
+        (2000, 400000, 384, 8, 0, 0), (2000, 400000, 128, 8, 0, 0), (3000, 500000, 64, 8, 0, 2),
     ]
     try:
         for V, E, F, nb, rows, skew in cases:
@@ -909,8 +911,9 @@ def test_sweep_variant_random_shapes(da):
             ctx.aggregate(1, da.BACKWARD)
             ref_f = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], x)
             ref_b = orc.aggregate_gcn(g["rowPtr"], g["colIdx"], g["csrVal"], g["norm"], gr)
-            assert rel_err(ctx.download(0, "ah"), ref_f) < 1e-5, (V, E, F, nb, rows, skew)
-            assert rel_err(ctx.download(0, "aTg"), ref_b) < 1e-5, (V, E, F, nb, rows, skew)
+            tol = 5e-5 if skew == 2 else 1e-5      # power law: rows of 1e4-1e5 terms, summed in pieces (fp32 reassociation)
+            assert rel_err(ctx.download(0, "ah"), ref_f) < tol, (V, E, F, nb, rows, skew)
+            assert rel_err(ctx.download(0, "aTg"), ref_b) < tol, (V, E, F, nb, rows, skew)
             ctx.close()
     finally:
         c = da.Context(0)
