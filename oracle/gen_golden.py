@@ -195,6 +195,9 @@ def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
         store[f"W{l}"] = Ws[l]
     for k, v in out.items():
         store[k] = v.astype(np.float32) if k.startswith("dW") else v[sample].astype(np.float32)
+    # the complete gradient entering the backward half (the GPU test uploads it as "grad"@(L-1) and compares aTg, g, grad
+    # and dW of the layers below with the rows above directly)
+    store[f"grad{L-1}_full"] = out[f"grad{L-1}"].astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **store)
     print("numpy-gnn fixture", name, "written:", os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024, "KiB")
 

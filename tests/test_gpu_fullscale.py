@@ -327,3 +327,172 @@ def test_fullscale_amazon_aggregate_properties_and_epoch():
         assert np.isfinite(ctx.weight_get(l)).all()
     eng.close()
     ctx.close()
+
+
+# ---- one rank of an 8-way split at the real sizes of BASELINE configs 4 and 5 ------------------------------------------
+def _oracle_rows_partition(g, ptr_key, idx_key, val_key, rows, seed_local, seed_ghost, ghost_key, F):
+    """oracle aggregate of sampled rows of a partition WITH ghost sources: the source rows the sample touches are
+    regenerated on the host from the counter RNG the device tensors were filled with (keyed by global vertex id), so no
+    ghost tensor (tens of GB) has to come back to the host."""
+    import orc
+    from helpers import splitmix_uniform
+    N = int(g["localVtxCnt"])
+    ptr = g[ptr_key]
+    segs = [(int(ptr[v]), int(ptr[v + 1])) for v in rows]
+    sub_ptr = np.concatenate([[0], np.cumsum([b - a for a, b in segs])]).astype(np.uint64)
+    idx = np.concatenate([g[idx_key][a:b] for a, b in segs]).astype(np.int64)
+    val = np.concatenate([g[val_key][a:b] for a, b in segs]).astype(np.float32)
+    uniq, inv = np.unique(idx, return_inverse=True)
+    loc = uniq < N
+    table = np.empty((uniq.size, F), np.float32)
+    table[loc] = splitmix_uniform(seed_local, g["localToGlobal"][uniq[loc]], F)
+    table[~loc] = splitmix_uniform(seed_ghost, g[ghost_key][uniq[~loc] - N], F)
+    n = len(rows)
+    self_rows = splitmix_uniform(seed_local, g["localToGlobal"][rows], F)
+    out = np.empty((n, F), np.float32)
+    orc.lib.orc_aggregate_gcn(n, F, sub_ptr, (inv + n).astype(np.uint32), val, np.ascontiguousarray(g["norm"][rows]),
+                              np.ascontiguousarray(self_rows), table, out)
+    return out, int((~loc).sum())
+
+
+def _sample_rows(g, ptr_key, idx_key, n, seed):
+    """n random rows + the 10 highest-degree rows + first/last + rows that certainly read ghost sources"""
+    N = int(g["localVtxCnt"])
+    rng = np.random.default_rng(seed)
+    deg = np.diff(g[ptr_key].astype(np.int64))
+    rows = np.unique(np.concatenate([rng.integers(0, N, n), np.argsort(deg)[-10:], [0, N - 1]]))
+    ptr = g[ptr_key].astype(np.int64)
+    with_ghost = sum(bool((g[idx_key][ptr[v]:ptr[v + 1]] >= N).any()) for v in rows)
+    return rows, with_ghost
+
+
+def _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers, bwd_layer):
+    """forward aggregate at layer 0 (widest rows, fg@0 ghosts) and at a hidden layer, backward aggregate at `bwd_layer`
+    (bg ghosts): sampled rows vs the oracle, float64 checksum of checksums with the real ghost rows, bit-exact scale
+    covariance, then whole learning epochs (exchange-free: one rank alone) that stay finite."""
+    from helpers import rel_err, splitmix_uniform
+    N, Gs, Gd = int(g["localVtxCnt"]), int(g["srcGhostCnt"]), int(g["dstGhostCnt"])
+    ctx = da.Context(0)
+    ctx.configure(da.GCN, dims, V)
+    part.upload(ctx)
+    ctx.preallocate()
+    # ---- layer 0, forward: x (N x d0) and the file-loaded ghost rows fg@0 (Gs x d0) -----------------------------------
+    ctx.fill_uniform(0, "x", 11, -1.0, 1.0, g["localToGlobal"])
+    ctx.fill_uniform(0, "fg", 11, -1.0, 1.0, g["srcGhost"])
+    ctx.aggregate(0, da.FORWARD)
+    ah0 = ctx.download(0, "ah")
+    rows, with_ghost = _sample_rows(g, "colPtr", "rowIdx", 1500, 0)
+    assert rows.size >= 1500 and with_ghost > 0.9 * rows.size          # nearly every row gathers ghost rows
+    ref, nghost_src = _oracle_rows_partition(g, "colPtr", "rowIdx", "cscVal", rows, 11, 11, "srcGhost", dims[0])
+    assert nghost_src > 0
+    assert rel_err(ah0[rows], ref) < 1e-4
+    assert np.array_equal(ctx.download(0, "x")[rows], splitmix_uniform(11, g["localToGlobal"][rows], dims[0]))
+    # scale covariance, bit-exact over the whole tensor: aggregate(2x, 2fg) == 2 aggregate(x, fg)
+    ctx.fill_uniform(0, "x", 11, -2.0, 2.0, g["localToGlobal"])
+    ctx.fill_uniform(0, "fg", 11, -2.0, 2.0, g["srcGhost"])
+    ctx.aggregate(0, da.FORWARD)
+    ah0 *= np.float32(2.0)
+    assert np.array_equal(ctx.download(0, "ah"), ah0)
+    del ah0
+    # ---- hidden layers, forward: h@(l-1) and fg@l, with the float64 checksum of checksums over ALL sources -----------
+    for l in agg_fwd_layers:
+        F = dims[l]
+        ctx.fill_uniform(l - 1, "h", 20 + l, -1.0, 1.0, g["localToGlobal"])
+        ctx.fill_uniform(l, "fg", 20 + l, -1.0, 1.0, g["srcGhost"])
+        ctx.aggregate(l, da.FORWARD)
+        ah = ctx.download(l, "ah")
+        ref, _ = _oracle_rows_partition(g, "colPtr", "rowIdx", "cscVal", rows, 20 + l, 20 + l, "srcGhost", F)
+        assert rel_err(ah[rows], ref) < 1e-4, l
+        w = np.bincount(g["rowIdx"], weights=g["cscVal"].astype(np.float64), minlength=N + Gs)
+        w[:N] += g["norm"].astype(np.float64)
+        H = ctx.download(l - 1, "h")
+        FG = ctx.download(l, "fg")
+        expect = w[:N] @ H.astype(np.float64)
+        for a in range(0, Gs, 1 << 22):
+            expect += w[N + a:N + min(Gs, a + (1 << 22))] @ FG[a:a + (1 << 22)].astype(np.float64)
+        got = ah.sum(0, dtype=np.float64)
+        assert np.abs(got - expect).max() / np.abs(expect).max() < 1e-5, l
+        del ah, H, FG
+    # ---- backward aggregate: grad@l over the CSR with the ghost destinations' rows in bg@(l-1) -------------------------
+    l = bwd_layer
+    F = dims[l]
+    ctx.fill_uniform(l, "grad", 31, -1.0, 1.0, g["localToGlobal"])
+    ctx.fill_uniform(l - 1, "bg", 31, -1.0, 1.0, g["dstGhost"])
+    ctx.aggregate(l, da.BACKWARD)
+    aTg = ctx.download(l - 1, "aTg")
+    rows_b, with_ghost_b = _sample_rows(g, "rowPtr", "colIdx", 1500, 1)
+    assert with_ghost_b > 0.9 * rows_b.size
+    refb, _ = _oracle_rows_partition(g, "rowPtr", "colIdx", "csrVal", rows_b, 31, 31, "dstGhost", F)
+    assert rel_err(aTg[rows_b], refb) < 1e-4
+    ctx.fill_uniform(l, "grad", 31, -2.0, 2.0, g["localToGlobal"])
+    ctx.fill_uniform(l - 1, "bg", 31, -2.0, 2.0, g["dstGhost"])
+    ctx.aggregate(l, da.BACKWARD)
+    aTg *= np.float32(2.0)
+    assert np.array_equal(ctx.download(l - 1, "aTg"), aTg)
+    del aTg
+    # ---- whole epochs of this rank alone (ghost rows of the hidden layers stay as filled: no peers to exchange with) ---
+    ctx.fill_uniform(0, "x", 1, -1.0, 1.0, g["localToGlobal"])
+    ctx.fill_uniform(0, "fg", 1, -1.0, 1.0, g["srcGhost"])
+    ctx.labels_upload(np.random.default_rng(2).integers(0, dims[-1], N).astype(np.uint32))
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    losses = []
+    for _ in range(3):
+        eng.run(1)
+        a, lo, n = ctx.train_stat()
+        assert np.isfinite(lo) and n == int(N * 0.1)
+        losses.append(lo / n)
+    assert losses[-1] < losses[0]
+    for l in range(len(dims) - 1):
+        assert np.isfinite(ctx.weight_get(l)).all()
+    assert np.isfinite(ctx.download(0, "aTg")).all()
+    eng.close()
+    ctx.close()
+
+
+def test_fullscale_amazon_rank_partition():
+    """BASELINE config 4 as ONE RANK OF 8 sees it: the whole Amazon-size graph (9 430 088 vertices, ~231.6 M records) is
+    generated, rank 0's contiguous block is built by dory_partition_build with its real ghost sets (~1.18 M local rows,
+    ~7.8 M source ghosts), and the 3-layer 300-64-64-25 path runs on it."""
+    import dorylus_amd as da
+    from bench import WORKLOADS, synth_edges
+    V, E, dims = WORKLOADS["amazon"]
+    P = 8
+    src, dst = synth_edges("uniform", V, E)
+    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+    part = da.Partition.build(src, dst, parts, 0, P)
+    del src, dst
+    g = part.view()
+    N, Gs = int(g["localVtxCnt"]), int(g["srcGhostCnt"])
+    assert abs(N - V // P) <= 1 and Gs > 7_000_000 and int(g["localInEdgeCnt"]) > 2.7e7
+    _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers=(1, 2), bwd_layer=2)
+
+
+def test_fullscale_friendster_rank_partition():
+    """BASELINE config 5 (Friendster: 65 608 366 vertices, ~3.61 G records, 256-48-51) as rank 0 of 8 holds it.  Only the
+    records incident to rank 0's block are generated -- a record (s, d) matters to a rank iff s or d is local, and the
+    3.6 G-record list would be 29 GB of host memory for nothing: M undirected pairs {a, b}, a uniform in the block, b
+    uniform in V, both directions emitted, M chosen so that the block's in-edge count is the real E/8 (451.5 M).  The
+    partition then has the real shape: ~8.2 M local rows, ~57 M source ghosts (almost every other vertex), ~451 M
+    in-edges; dory_partition_build sees exactly the reference's record format (degrees of the ghosts are those of this
+    record list)."""
+    import dorylus_amd as da
+    from bench import WORKLOADS
+    V, E, dims = WORKLOADS["friendster"]
+    P = 8
+    NB = V // P                                     # rank 0 owns [0, NB) under the contiguous split below
+    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+    assert parts[NB - 1] == 0 and parts[NB + 1] == 1
+    M = int(E / P * P / (P + 1))                    # in-edges of the block = M (b -> a) + M/P (a -> b with b local)
+    rng = np.random.default_rng(42)
+    a = rng.integers(0, NB, M, dtype=np.uint32)
+    b = rng.integers(0, V, M, dtype=np.uint32)
+    src, dst = np.concatenate([a, b]), np.concatenate([b, a])
+    del a, b
+    part = da.Partition.build(src, dst, parts, 0, P)
+    del src, dst
+    g = part.view()
+    N, Gs, nnz = int(g["localVtxCnt"]), int(g["srcGhostCnt"]), int(g["localInEdgeCnt"])
+    assert abs(N - NB) <= 1 and Gs > 5.5e7 and abs(nnz - E / P) < 0.01 * E / P
+    _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers=(1,), bwd_layer=1)
