@@ -343,13 +343,139 @@ static void run_pair(const float4 *dx, uint32_t win_rows, uint32_t stride4, floa
     CK(hipFree(dn));
 }
 
-int main() {
+// wave stream ("K1w"): the R rows of a WAVE are one stream of entries; instruction i carries entries 2i (lanes 0-31) and
+// 2i+1 (lanes 32-63); batches of U instructions are always full and straddle row boundaries; a batch is applied to every
+// row it overlaps (static accumulator per row, unrolled) with per-lane masks by entry index.  No per-row tails, no
+// divergence between the halves.  Row offsets come from LDS as in spmm_sweep_kernel.  Rate counts the entries gathered.
+template <int U, int R, int LO, int SPAN>
+__global__ __launch_bounds__(1024) void k1w_probe(const float4 *__restrict__ x, uint32_t win_rows, uint32_t stride4, int iters,
+                                                  float4 *__restrict__ out, unsigned long long *__restrict__ nent) {
+    __shared__ uint2 stage[16][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t row_b = stride4 * 16u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4 *>(x + (size_t)xcd * win_rows * stride4), 0, win_rows * row_b, 0x00020000);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t state = (blockIdx.x * 16 + wave) * 2654435761u + 12345u;
+    for (int i = lane; i < 512; i += 64) {
+        uint32_t st2 = state + i * 7919u;
+        st2 = st2 * 1664525u + 1013904223u;
+        stage[wave][i] = make_uint2((uint32_t)(((uint64_t)(st2 >> 4) * win_rows) >> 28), 0x3f800000u);
+    }
+    __syncthreads();
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint2 *st = stage[wave];
+    uint32_t cnt = 0;
+    for (int it = 0; it < iters; ++it) {
+        // row offsets of this step: lane l holds the offset of row l (exclusive scan of the lengths), lane R the total
+        uint32_t my_off;
+        {
+            uint32_t s2 = (state + (uint32_t)it * 977u + (uint32_t)lane * 7919u) * 1664525u + 1013904223u;
+            uint32_t n = lane < R ? LO + (s2 >> 8) % SPAN : 0u;
+            uint32_t pre = n;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)pre, d, 64);
+                if (lane >= d) pre += t;
+            }
+            my_off = pre - n;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)my_off, R);
+        cnt += total;
+        uint32_t bpos = 0;
+        float w[U];
+        u4 v[U];
+        bool need = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r + 1);
+            if (s == e) continue;
+            do {
+                if (need) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint2 en = st[(bpos + 2 * u + h) & 511];
+                        w[u] = __uint_as_float(en.y);
+                        uint32_t off = __umul24(en.x, row_b) + li * 16u;
+                        off = bpos + 2 * u + h < total ? off : 0xFFFFFFFFu;
+                        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                    }
+                    need = false;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t ei = bpos + 2 * u + h;
+                    const float wm = (ei - s < e - s) ? w[u] : 0.f;
+                    acc[r].x += wm * __uint_as_float(v[u].x); acc[r].y += wm * __uint_as_float(v[u].y);
+                    acc[r].z += wm * __uint_as_float(v[u].z); acc[r].w += wm * __uint_as_float(v[u].w);
+                }
+                if (bpos + 2 * U > e) break;          // the row ends inside this batch: the next row shares it
+                bpos += 2 * U;                        // batch used up
+                need = true;
+            } while (bpos < e);
+        }
+    }
+    float4 t = acc[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t = add4(acc[r], t);
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = t;
+    if (lane == 0) atomicAdd(nent, (unsigned long long)cnt);
+}
+
+template <int U, int R, int LO, int SPAN>
+static void run_k1w(const float4 *dx, uint32_t win_rows, uint32_t stride4, float4 *dout) {
+    const int nwg = 256, iters = 8000 / (10 * R);
+    unsigned long long *dn, hn = 0;
+    CK(hipMalloc(&dn, 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(dn, 0, 8));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k1w_probe<U, R, LO, SPAN>), dim3(nwg), dim3(1024), 0, 0, dx, win_rows, stride4, iters, dout, dn);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(&hn, dn, 8, hipMemcpyDeviceToHost));
+    const double bytes = (double)hn * 512;
+    printf("k1w wave stream: U=%d R=%2d row length %d..%d: %7.3f ms  %6.2f TB/s\n", U, R, LO, LO + SPAN - 1, ms, bytes / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+    CK(hipFree(dn));
+}
+
+int main(int argc, char **argv) {
+    const bool only_new = argc > 1;
     const uint32_t stride4 = 152;                 // 608 floats per row, as x at F=602
     const size_t rows_total = 8u * 65536u;
     float4 *dx, *dout;
     CK(hipMalloc(&dx, rows_total * stride4 * 16));
     CK(hipMemset(dx, 0, rows_total * stride4 * 16));
     CK(hipMalloc(&dout, (size_t)256 * 8 * 256 * 16));
+    if (only_new) {
+        printf("-- references: fixed full batches, K1s row loop, paired halves\n");
+        run_k1s<4, 10, 1>(dx, 4096, stride4, dout);
+        run_rows<4, 10, 4, 13>(dx, 4096, stride4, dout);
+        run_pair<4, 10, 4, 13>(dx, 4096, stride4, dout);
+        printf("-- wave stream\n");
+        run_k1w<4, 16, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<4, 20, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<4, 10, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<2, 16, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<3, 16, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<6, 16, 4, 13>(dx, 4096, stride4, dout);
+        run_k1w<4, 16, 1, 19>(dx, 4096, stride4, dout);
+        run_k1w<4, 16, 2, 7>(dx, 4096, stride4, dout);
+        run_k1w<4, 16, 8, 25>(dx, 4096, stride4, dout);
+        return 0;
+    }
     // window sizes in rows chosen for ~2 MB of touched bytes
     printf("-- registers, 2 MB window, lanes/row x in-flight\n");
     run<8, 4, 0>(dx, 16384, stride4, dout, 8);
