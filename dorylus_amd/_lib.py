@@ -24,7 +24,7 @@ SYMBOLS = [
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
     "dory_gatmh_heads", "dory_transform_first_active", "dory_transform_first_layer",
-    "dory_comm_set_host_transport",
+    "dory_comm_set_host_transport", "dory_debug_occupy_cus",
 ]
 
 # host transport callbacks (include/dorylus_hip.h)
@@ -52,6 +52,7 @@ def load():
         "dory_create": [i32, C.POINTER(vp)],
         "dory_destroy": [vp],
         "dory_set_streams": [vp, vp, vp],
+        "dory_debug_occupy_cus": [vp, u32, u64],
         "dory_sync": [vp],
         "dory_configure": [vp, i32, u32, vp, u32, u32, u32],
         "dory_graph_upload": [vp, u32, u32, u32, u64, vp, vp, vp, u64, vp, vp, vp, vp],
@@ -351,6 +352,9 @@ class Context:
     # -- misc -----------------------------------------------------------------------------------
     def sync(self):
         self._ck(self.lib.dory_sync(self.h))
+
+    def debug_occupy_cus(self, workgroups, usec):
+        self._ck(self.lib.dory_debug_occupy_cus(self.h, workgroups, usec))
 
     def set_streams(self, compute=None, comm=None):
         self._ck(self.lib.dory_set_streams(self.h, C.c_void_p(compute or 0), C.c_void_p(comm or 0)))

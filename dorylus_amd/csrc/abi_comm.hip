@@ -133,6 +133,7 @@ int dory_halo_pack(dory_ctx *c, uint32_t layer, int dir, float *send_buf) {
 
 int dory_halo_unpack(dory_ctx *c, uint32_t layer, int dir, const float *recv_buf) {
     CHECK_CTX(c);
+    if (layer == 0) c->ah0_valid = false;   // (a caller's transport writing fg@0)
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
@@ -251,6 +252,7 @@ int dory_halo_pack_tensor(dory_ctx *c, uint32_t layer, const char *name, int dir
 
 int dory_halo_unpack_tensor(dory_ctx *c, uint32_t layer, const char *name, int dir, const float *recv_buf) {
     CHECK_CTX(c);
+    if (layer == 0) c->ah0_valid = false;   // (a caller's transport writing fg@0)
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *ghost = name ? find(c, layer, name) : nullptr;
     if (!ghost || (dir != 0 && dir != 1) || !c->plan[dir].set) return fail(c, DORY_ERR_ARG, "halo_unpack_tensor: no tensor '%s'@%u or no plan", name ? name : "(null)", layer);

@@ -148,16 +148,18 @@ int dory_create(int device, dory_ctx **out) {
         hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->d_stat, 2 * sizeof(float)) != hipSuccess) {
+        hipMalloc((void **)&c->d_stat, 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&c->sweep_stat, 4 * sizeof(uint32_t)) != hipSuccess) {
         delete c;
         return fail(nullptr, DORY_ERR_HIP, "stream/event creation failed");
     }
     (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
+    (void)hipMemset(c->sweep_stat, 0, 4 * sizeof(uint32_t));
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
     c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
-    c->opt["spmm_sweep_rows"] = 0;
-    c->opt["spmm_sweep_pair"] = -1;          // K1s: two rows of a lane group as one stream of entries: -1 = launches of >= 3 slabs, 0 = never, 1 = always           // K1s: rows per lane group, 0 = by fill (2/4/6/8/10; process-wide, for tests and experiments)
+    c->opt["spmm_sweep_rows"] = 0;           // K1s: rows per lane group, 0 = by fill (2/4/6/8/10; tests and experiments)
+    c->opt["spmm_sweep_pair"] = -1;          // K1s: two rows of a lane group as one stream of entries: -1 = launches of >= 3 slabs, 0 = never, 1 = always
     c->opt["spmm_sweep_reserve_cus"] = 4;    // K1s under an exchange in flight: CUs per XCD its sweeps leave to the RCCL kernels
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
@@ -170,6 +172,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
     c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
+    c->opt["gcn_cache_ah0"] = 0;         // GCN: keep ah@0 = A_hat x across epochs while x, fg@0 and the adjacency are unchanged (opt-in; the reference recomputes it)
     c->opt["gcn_transform_first"] = 0;   // GCN layers as A(XW) instead of (AX)W where the input is wider than the output: 1 = layer 0, 2 = all (see tf_layer)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone
     c->opt["spmm_blk_nb"] = 0;       // K1b: number of source blocks (0 = auto, ~3.75 MB windows)
@@ -230,6 +233,7 @@ int dory_destroy(dory_ctx *c) {
     if (c->send_buf) (void)hipFree(c->send_buf);
     if (c->recv_buf) (void)hipFree(c->recv_buf);
     if (c->d_stat) (void)hipFree(c->d_stat);
+    if (c->sweep_stat) (void)hipFree(c->sweep_stat);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->own_compute && c->compute) (void)hipStreamDestroy(c->compute);
@@ -298,6 +302,7 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
                       uint64_t nnz_out, const uint64_t *row_ptrs, const uint32_t *column_idxs,
                       const float *csr_values, const float *vtx_norms) {
     CHECK_CTX(c);
+    c->ah0_valid = false;
     if (!column_ptrs || !row_ptrs || (N && !vtx_norms) || (nnz_in && (!row_idxs || !csc_values)) ||
         (nnz_out && (!column_idxs || !csr_values)))
         return fail(c, DORY_ERR_ARG, "dory_graph_upload: null array");
@@ -357,6 +362,7 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
 
 int dory_preallocate(dory_ctx *c) {
     CHECK_CTX(c);
+    c->ah0_valid = false;
     if (!c->configured || !c->has_graph) return fail(c, DORY_ERR_ARG, "dory_preallocate: configure and graph_upload first");
     epoch_graph_drop_locked(c);   // a recorded epoch points at the tensors freed below
     HIPCK(c, hipDeviceSynchronize());
@@ -504,7 +510,7 @@ int dory_preallocate(dory_ctx *c) {
             if ((rc = ensure_sweep(c, false, group))) return rc;
             size_t need = 0;
             for (const BlockedAdj *S : {&c->swpIn, &c->swpOut})
-                if (S->nb) need = std::max(need, sweep_scratch_bytes(*S, maxld, group, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb));
+                if (S->nb) need = std::max(need, sweep_scratch_bytes(*S, maxld, group, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb, (int)c->opt["spmm_sweep_rows"]));
             if (need > c->partial_bytes) {
                 if (c->partial) (void)hipFree(c->partial);
                 c->partial = nullptr;
@@ -512,6 +518,10 @@ int dory_preallocate(dory_ctx *c) {
                 HIPCK(c, hipMalloc((void **)&c->partial, need));
                 c->partial_bytes = need;
             }
+            // the slots of the split rows' pieces too (skewed graphs): an epoch recorded into a hipGraph right after a
+            // re-upload must not find anything left to allocate
+            const uint32_t nslots = std::max(c->swpIn.nslots, c->swpOut.nslots);
+            if (nslots && (rc = ensure_scratch(c, (size_t)nslots * maxld * sizeof(float)))) return rc;
         } else if (minld >= 32) {
             if ((rc = ensure_blocked(c, true, group))) return rc;
             if ((rc = ensure_blocked(c, false, group))) return rc;
@@ -579,6 +589,7 @@ int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const floa
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_upload: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (layer == 0) c->ah0_valid = false;                                    // x / fg@0 / ah@0 may have changed
     if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
     if (!strcmp(name, "dA") && layer < c->gat_drow_valid.size()) c->gat_drow_valid[layer] = 0;
     return upload_dense(c, *t, host);
@@ -598,6 +609,7 @@ int dory_tensor_fill_uniform(dory_ctx *c, uint32_t layer, const char *name, uint
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t) return fail(c, DORY_ERR_ARG, "tensor_fill: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (layer == 0) c->ah0_valid = false;
     uint32_t *ids = nullptr;
     if (global_row_ids && t->rows) {
         int rc = upload_array(c, &ids, global_row_ids, t->rows);
@@ -696,6 +708,14 @@ int dory_timing_enable(dory_ctx *c, int on) {
 int dory_timing_get(dory_ctx *c, const char *family, double *total_ms, uint64_t *launches) {
     CHECK_CTX(c);
     if (!family) return DORY_ERR_ARG;
+    if (!strcmp(family, "spmm_gate_timeouts")) {   // not a kernel family: launches = gate timeouts, total_ms = ungated launches
+        uint32_t st[4] = {0, 0, 0, 0};
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
+        if (total_ms) *total_ms = (double)st[2];
+        if (launches) *launches = st[0];
+        return DORY_OK;
+    }
     drain_timing(c);
     auto it = c->times.find(family);
     if (total_ms) *total_ms = it == c->times.end() ? 0.0 : it->second.total_ms;
@@ -725,8 +745,22 @@ int dory_transform_first_layer(dory_ctx *c, uint32_t layer) {
 
 int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     CHECK_CTX(c);
+    if (key && value && !strcmp(key, "gcn_cache_ah0_skips")) {   // read-only: layer-0 aggregations answered from the cached ah@0
+        *value = (int64_t)c->ah0_skips;
+        return DORY_OK;
+    }
     if (key && value && !strcmp(key, "epoch_graph_recorded")) {   // read-only: does the ctx still hold a recorded epoch?
         *value = c->epoch_exec ? 1 : 0;
+        return DORY_OK;
+    }
+    // read-only counters of the K1s gates (device words that outlive the launches): timeouts = a sweep's workgroups were
+    // not co-resident within the polling bound; ungated launches = launches that ran without gates while the context
+    // backed off after a timeout (same results, unsynchronised rate)
+    if (key && value && (!strcmp(key, "spmm_gate_timeouts") || !strcmp(key, "spmm_ungated_launches"))) {
+        uint32_t st[4] = {0, 0, 0, 0};
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
+        *value = !strcmp(key, "spmm_gate_timeouts") ? st[0] : st[2];
         return DORY_OK;
     }
     if (!key || !value || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
@@ -734,12 +768,18 @@ int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     return DORY_OK;
 }
 
+int dory_debug_occupy_cus(dory_ctx *c, uint32_t workgroups, uint64_t usec) {
+    CHECK_CTX(c);
+    if (usec > 2000000) return fail(c, DORY_ERR_ARG, "debug_occupy_cus: at most 2 s");
+    HIPCK(c, launch_occupy_cus(workgroups, usec, c->comm));
+    return DORY_OK;
+}
+
 int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
     CHECK_CTX(c);
     if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
     c->opt[key] = value;
-    if (!strcmp(key, "spmm_sweep_rows")) sweep_force_rows((int)value);   // process-wide (a test / experiment knob)
-    if (!strcmp(key, "spmm_sweep_pair")) sweep_force_pair((int)value);   // likewise: -1 = by the number of slabs, 0 / 1
+    c->ah0_valid = false;   // (another kernel variant sums in another order: a cached ah@0 is only kept across identical settings)
     return DORY_OK;
 }
 

@@ -47,7 +47,7 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     bool &built = csc ? c->swpIn_built : c->swpOut_built;
     bool &na = csc ? c->swpIn_na : c->swpOut_na;
     const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
-    if (built && want_nb && S.nb != want_nb && !c->capturing) {     // an explicit block count (tests) forces a rebuild
+    if (built && (csc ? c->swpIn_want_nb : c->swpOut_want_nb) != want_nb && !c->capturing) {     // another block count requested (tests): rebuild
         HIPCK(c, hipStreamSynchronize(c->compute));
         free_blocked(&S);
         built = false;
@@ -65,10 +65,11 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
         na = true;
         return DORY_OK;
     }
-    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd));   // the deal is made for the 32-lane launches
+    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);   // the deal is made for the 32-lane launches
     HIPCK(c, build_blocked_sweep(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal, c->N,
                                  NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, window, R, &S, c->compute,
                                  (uint32_t)c->opt["spmm_sweep_layout"], std::min<uint32_t>(32u, c->cus_per_xcd)));
+    (csc ? c->swpIn_want_nb : c->swpOut_want_nb) = want_nb;
     built = true;
     return DORY_OK;
 }
@@ -110,7 +111,8 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             // With ghost rows the blocks that hold local rows only always run as a launch of their own (they do not
             // depend on an exchange in flight), so the overlapped and the sequential schedule are the same arithmetic.
             const bool two = a.xg != nullptr && S.nb_local > 0 && S.nb_local < S.nb;
-            const size_t need = sweep_scratch_bytes(S, a.ld, group, G, two ? std::max(S.nb_local, S.nb - S.nb_local) : S.nb);
+            const int force_r = (int)c->opt["spmm_sweep_rows"];
+            const size_t need = sweep_scratch_bytes(S, a.ld, group, G, two ? std::max(S.nb_local, S.nb - S.nb_local) : S.nb, force_r);
             if (need > c->partial_bytes) {
                 if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: sweep counters would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));
@@ -124,19 +126,26 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             Timed t(c, "spmm", c->compute);
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
             const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+            SweepCtl ctl;
+            ctl.force_r = force_r;
+            ctl.pair = (int)c->opt["spmm_sweep_pair"];
+            ctl.stat = c->sweep_stat;
             SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
             if (two) {
                 // under an exchange in flight the RCCL kernels need CUs of their own
                 const uint32_t reserve = c->halo_pending ? (uint32_t)c->opt["spmm_sweep_reserve_cus"] : 0u;
-                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, sflags, c->scratch, reserve));
+                ctl.seq = c->sweep_seq++;
+                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, ctl, sflags, c->scratch, reserve));
                 if ((rc = wait_halo(c))) return rc;
                 SpmmArgs a2 = a;
                 a2.self_mode = 0;
                 a2.accumulate = 1;
-                HIPCK(c, launch_spmm_sweep(a2, S, group, row_scale, G, S.nb_local, S.nb, done, c->compute, sflags | 2u, c->scratch));
+                ctl.seq = c->sweep_seq++;
+                HIPCK(c, launch_spmm_sweep(a2, S, group, row_scale, G, S.nb_local, S.nb, done, c->compute, ctl, sflags | 2u, c->scratch));
             } else {
                 if ((rc = wait_halo(c))) return rc;
-                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb, done, c->compute, sflags, c->scratch));
+                ctl.seq = c->sweep_seq++;
+                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb, done, c->compute, ctl, sflags, c->scratch));
             }
             HIPCK(c, launch_spmm_sweep_combine(a, S, row_scale, c->scratch, c->compute));
             return DORY_OK;
@@ -241,6 +250,17 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 }   // deeper layers: apply_vertex(l-1) left xw@l, the forward exchange of layer l its ghost rows
                 return spmm(c, true, c->cscVal, 1, *xw, fgxw, *z, c->dims[layer + 1], 0);
             }
+            // Opt-in "gcn_cache_ah0" (no reference counterpart; the reference recomputes it every epoch and so does the
+            // default here): in full-graph training ah@0 = A_hat [x ; fg@0] is a constant of the run -- x and fg@0 come
+            // from files, the adjacency never changes -- and with 288 GB of HBM it can simply stay.  The aggregation of
+            // layer 0 is skipped while nothing it reads has been written through this ABI since it was last computed.
+            if (layer == 0 && c->opt["gcn_cache_ah0"] && !c->capturing) {
+                if (c->ah0_valid) { c->ah0_skips++; return DORY_OK; }
+                int rc = spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+                c->ah0_valid = rc == DORY_OK;
+                return rc;
+            }
+            if (layer == 0) c->ah0_valid = false;
             return spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
         }
         if (tf_layer(c, layer)) {   // u_l = A^T g_l (ghost rows of g_l: backward exchange of layer l); dW_l = in_l^T u_l

@@ -125,9 +125,12 @@ struct dory_ctx {
     dory::BlockedAdj blkIn, blkOut;
     dory::BlockedAdj swpIn, swpOut;             // K1s layouts (built on first use when spmm_variant == 2)
     bool swpIn_built = false, swpOut_built = false, swpIn_na = false, swpOut_na = false;
+    uint32_t swpIn_want_nb = 0, swpOut_want_nb = 0;   // the spmm_blk_nb the layouts were built for
     bool blkIn_built = false, blkOut_built = false;
     bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
     uint32_t cus_per_xcd = 32;                  // K1s: workgroups per sweep
+    uint32_t *sweep_stat = nullptr;             // K1s: 4 device words (gate timeouts, backoff horizon, ungated launches, spare)
+    uint32_t sweep_seq = 0;                     // K1s: launches so far
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
     float *partial = nullptr;
@@ -135,6 +138,8 @@ struct dory_ctx {
 
     // tensors / weights
     bool prealloc = false;
+    bool ah0_valid = false;      // option gcn_cache_ah0: ah@0 holds the aggregate of the current x / fg@0 / adjacency
+    uint64_t ah0_skips = 0;      // layer-0 aggregations answered from it
     std::vector<std::map<std::string, dory::Tensor>> tensors;   // [layer][name]
     std::vector<std::map<std::string, dory::Tensor>> weights;   // "w", "a_i"
     std::vector<std::map<std::string, dory::Tensor>> wgrads;    // same names
@@ -222,20 +227,27 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
                                BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */,
                                uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */);
-int sweep_pick_r(uint32_t N, int group, uint32_t G);
+int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r = 0 /* option spmm_sweep_rows: 0 = by fill */);
 // host/sweep_deal.cpp: rows per lane group of the K1s layout and the position of every (sorted) item
 bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos);
 bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);
-void sweep_force_rows(int r);   // process-wide: rows per lane group (0 = auto)
-void sweep_force_pair(int p);   // process-wide: rows in pairs (-1 = by the number of slabs)
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
-size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks);
+// per-context knobs and state of the K1s launches (nothing process-wide)
+struct SweepCtl {
+    int force_r = 0;            // option spmm_sweep_rows
+    int pair = -1;              // option spmm_sweep_pair
+    uint32_t *stat = nullptr;   // 4 device words that outlive the launches: gate timeouts, launch number that gates again,
+                                // ungated launches, spare
+    uint32_t seq = 0;           // launch number
+};
+size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks, int force_r = 0);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s,
-                             uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */,
+                             const SweepCtl &ctl, uint32_t flags = 0, float *split_partial = nullptr /* B.nslots x ld floats */,
                              uint32_t reserve_cus = 0 /* CUs per XCD left to concurrent kernels */);
 hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
                                      hipStream_t s);
+hipError_t launch_occupy_cus(uint32_t workgroups, uint64_t usec, hipStream_t s);   // diagnostic (dory_debug_occupy_cus)
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
                                const float *row_scale /*nullable: unit edge weights, per-row factor*/, hipStream_t s);

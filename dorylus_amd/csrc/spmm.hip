@@ -777,7 +777,15 @@ constexpr int SWEEP_NT = 1024;
 constexpr int SWEEP_C = 128;             // staged (idx,val) pairs per lane group and pass
 constexpr int SWEEP_U = 4;               // gathers per batch
 constexpr int SWEEP_SLACK = 1;           // start step b when all finished b - SWEEP_SLACK - 1
-constexpr uint32_t SWEEP_SPIN_LIMIT = 20000;
+// Polling is bounded.  One poll (eight serialised L1-bypassing loads + a short sleep) is 4-5 us.  A gate on a step of the
+// workgroup's own sweep waits for peers that are co-resident by assumption and at most a few steps behind: ~3 ms of
+// polls is two orders above any legitimate wait.  A gate on the PREVIOUS sweep (the first SWEEP_SLACK + 1 steps) may
+// legitimately wait for most of a sweep (surplus workgroups resident beside a sweep that left CUs to RCCL kernels):
+// its limit grows with the number of steps.  After a timeout the launch finishes ungated and the context keeps its gates
+// off for the next SWEEP_BACKOFF launches (the cause -- another process's kernels, a CU mask, RCCL holding more CUs than
+// reserved -- rarely goes away within one launch), then tries again.
+constexpr uint32_t SWEEP_SPIN_SHORT = 600, SWEEP_SPIN_PER_STEP = 40;
+constexpr uint32_t SWEEP_BACKOFF = 16;
 
 struct SweepArgs {
     uint32_t rpx;        // destination rows per XCD
@@ -788,6 +796,9 @@ struct SweepArgs {
     uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
     uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots); 8: no gates (diagnostic)
     float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
+    uint32_t *stat;      // per context, never reset by a launch: [0] gate timeouts, [1] first launch number that gates again,
+                         // [2] launches that ran (partly) ungated after a timeout, [3] spare
+    uint32_t seq;        // launch number of the context
 };
 
 template <int GROUP, int R, bool UNIT, bool PAIR>
@@ -816,6 +827,10 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const uint32_t nbs = w.b_hi - w.b_lo;
     uint32_t *dq = w.done + ((size_t)xcd * w.nsweeps + q) * nbs * 32;
     uint32_t *gates_off = w.done + (size_t)8 * w.nsweeps * nbs * 32;
+    // gates of this launch: off by request (diagnostic), or while the context backs off after a timeout
+    const bool gated = !(w.flags & 8u) && !(w.seq < __hip_atomic_load(w.stat + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (!gated && blockIdx.x == 0 && threadIdx.x == 0 && !(w.flags & 8u))
+        __hip_atomic_fetch_add(w.stat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % GROUP, gi = lane / GROUP;
     const int g = wave * GPW + gi;
@@ -875,16 +890,19 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
 
     for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
         const uint32_t sb = b - w.b_lo;                      // step of this launch
-        {   // gate
+        {   // gate: step sb may start once every workgroup of the sweep has finished step sb - SWEEP_SLACK - 1 (for the
+            // first steps: of the previous sweep of this XCD).  lds_allowed = number of steps this workgroup may start.
             const int bb = (int)sb - SWEEP_SLACK - 1;
-            const uint32_t *word = bb >= 0 ? dq + (size_t)bb * 32
-                                           : (q > 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
-            const uint32_t need = bb >= 0 ? cnt_q : cnt_p;
-            if (word && (int)nbs + bb >= 0 && lane == 0 && !(w.flags & 8u)) {   // flags bit 3: no gates (diagnostic)
-                while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sb) {
+            const bool prev = bb < 0;
+            const uint32_t *word = !prev ? dq + (size_t)bb * 32
+                                         : (q > 0 && (int)nbs + bb >= 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
+            const uint32_t need = !prev ? cnt_q : cnt_p;
+            if (word && lane == 0 && gated) {
+                const uint32_t limit = prev ? SWEEP_SPIN_SHORT + SWEEP_SPIN_PER_STEP * nbs : SWEEP_SPIN_SHORT;
+                while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
                     if (__hip_atomic_exchange(&lds_lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
                         uint32_t spins = 0;      // this wave polls for the workgroup
-                        while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sb) {
+                        while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
                             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                             uint32_t sum = 0;
 #pragma unroll
@@ -896,12 +914,18 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
                             }
                             if (sum >= need || __hip_atomic_load(gates_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                             __builtin_amdgcn_s_sleep(4);
-                            if (++spins > SWEEP_SPIN_LIMIT) {
-                                __hip_atomic_store(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (++spins > limit) {
+                                // the sweep's workgroups are not co-resident (or not on this XCD): the rest of this launch
+                                // and the context's next SWEEP_BACKOFF launches run ungated -- same results, counted
+                                if (__hip_atomic_exchange(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                    __hip_atomic_fetch_add(w.stat + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_fetch_max(w.stat + 1, w.seq + 1u + SWEEP_BACKOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                                 break;
                             }
                         }
-                        __hip_atomic_store(&lds_allowed, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (a wave at a later step may have raised it meanwhile: never lower it)
+                        __hip_atomic_fetch_max(&lds_allowed, sb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(&lds_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
                         __builtin_amdgcn_s_sleep(2);
@@ -1246,14 +1270,11 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     return hipSuccess;
 }
 
-// rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab
-static int g_sweep_force_r = 0;   // option spmm_sweep_rows (tests, experiments): 0 = pick by fill
-void sweep_force_rows(int r) { g_sweep_force_r = r; }
-static int g_sweep_pair = -1;     // option spmm_sweep_pair
-void sweep_force_pair(int p) { g_sweep_pair = p; }
-int sweep_pick_r(uint32_t N, int group, uint32_t G) {
-    if (g_sweep_force_r == 2 || g_sweep_force_r == 4 || g_sweep_force_r == 6 || g_sweep_force_r == 8 || (g_sweep_force_r == 10 && group == 32))
-        return g_sweep_force_r;
+// rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab;
+// force_r (option spmm_sweep_rows of the context; tests, experiments): 0 = pick by fill
+int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r) {
+    if (force_r == 2 || force_r == 4 || force_r == 6 || force_r == 8 || (force_r == 10 && group == 32))
+        return force_r;
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
     double best_fill = 0;
@@ -1278,16 +1299,16 @@ bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
 
 // rows per lane group of a launch: what the layout was dealt for, unless forced (option) or not instantiated for the
 // lane-group width
-static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G) {
-    const int forced = sweep_pick_r(0, group, G);      // (returns the forced value whatever N when one is set)
-    if (g_sweep_force_r && forced == g_sweep_force_r) return forced;
+static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G, int force_r) {
+    const int forced = sweep_pick_r(0, group, G, force_r);      // (returns the forced value whatever N when one is valid)
+    if (force_r && forced == force_r) return forced;
     if (B.rows_per_group && (group == 32 || B.rows_per_group <= 8)) return (int)B.rows_per_group;
-    return sweep_pick_r(B.npos, group, G);
+    return sweep_pick_r(B.npos, group, G, 0);
 }
 
 // counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
-size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks) {
-    const int R = sweep_rows_for(B, group, G);
+size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks, int force_r) {
+    const int R = sweep_rows_for(B, group, G, force_r);
     const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
     const uint32_t Gmin = G > 12 ? G - 8 : G;      // launches may leave up to 8 CUs per XCD to concurrent kernels
     const uint32_t rpx = (B.npos + 7) / 8 + 16, tiles = (rpx + RW - 1) / RW + 1, spp = (tiles + Gmin - 1) / Gmin;
@@ -1297,13 +1318,13 @@ size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t
 
 // out (+)= self + (row_scale *) sum over source blocks [b_lo, b_hi); `done` = sweep_scratch_bytes() of device memory
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus,
-                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, uint32_t flags,
+                             uint32_t b_lo, uint32_t b_hi, uint32_t *done, hipStream_t s, const SweepCtl &ctl, uint32_t flags,
                              float *split_partial, uint32_t reserve) {
     if (a.N == 0 || a.ld == 0 || b_lo >= b_hi) return hipSuccess;
-    if (!sweep_supported(a, B, group) || b_hi > B.nb || cus == 0 || cus > 32) return hipErrorInvalidValue;
+    if (!sweep_supported(a, B, group) || b_hi > B.nb || cus == 0 || cus > 32 || !ctl.stat) return hipErrorInvalidValue;
     if (b_lo < B.nb_local && b_hi > B.nb_local) return hipErrorInvalidValue;   // one source array per launch
     if (b_lo >= B.nb_local && !a.xg) return hipErrorInvalidValue;
-    const int R = sweep_rows_for(B, group, cus);
+    const int R = sweep_rows_for(B, group, cus, ctl.force_r);
     // A sweep is the workgroups that must be resident on an XCD together; each takes a whole CU (all its registers).
     // While other kernels hold CUs (the exchange's RCCL kernels under the local-source launch) fewer fit: a smaller
     // sweep leaves them room -- the surplus workgroups of the next sweep simply wait at their first gates.
@@ -1320,6 +1341,8 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     w.done = done;
     w.flags = flags;
     w.split_partial = split_partial;
+    w.stat = ctl.stat;
+    w.seq = ctl.seq;
     if (B.nslots && !split_partial) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(done, 0, ((size_t)8 * w.nsweeps * (b_hi - b_lo) * 32 + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -1327,8 +1350,8 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     const bool unit = row_scale != nullptr;
     // rows in pairs (one stream of entries per two rows) pay on launches of several slabs (five slabs, F=602: 13.8 ->
     // 13.3 ms; four: 11.0 -> 10.8; three: 8.16 -> 8.1), not on one or two (F=128: 2.70 -> 2.78; F=256: 5.43 -> 5.46);
-    // g_sweep_pair: -1 = that rule, 0 / 1 = forced (experiments)
-    const bool pair = g_sweep_pair < 0 ? slabs >= 3 : g_sweep_pair != 0;
+    // ctl.pair (option spmm_sweep_pair): -1 = that rule, 0 / 1 = forced (experiments)
+    const bool pair = ctl.pair < 0 ? slabs >= 3 : ctl.pair != 0;
 #define SWEEP_LAUNCH(GRP, RR)                                                                                          \
     do {                                                                                                               \
         if (unit) { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true>), gr, bl, 0, s, a, B, row_scale, w);   \
@@ -1345,6 +1368,25 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     else SWEEP_LAUNCH_R(16);
 #undef SWEEP_LAUNCH_R
 #undef SWEEP_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- diagnostic: hold CUs the way a concurrent kernel (an exchange's RCCL kernels, a co-tenant) would -----------------
+// `workgroups` workgroups of 1024 threads, all 128 registers per lane (nothing else fits beside one on a CU) and 96 KB of
+// LDS each, asleep for `ticks` of the 100 MHz wall clock.  K1s's sweeps then find fewer free CUs per XCD than they
+// assume: tests/test_gpu_gates.py.
+__global__ __launch_bounds__(1024) void occupy_cus_kernel(uint64_t ticks, uint32_t *sink) {
+    extern __shared__ uint32_t occupy_lds[];
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");   // a 128-register allocation: 4 waves per SIMD are the whole file
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (ticks == ~0ull) { occupy_lds[threadIdx.x] = 1; sink[0] = occupy_lds[0]; }
+}
+hipError_t launch_occupy_cus(uint32_t workgroups, uint64_t usec, hipStream_t s) {
+    if (!workgroups) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(occupy_cus_kernel, dim3(workgroups), dim3(1024), 96 << 10, s, usec * 100ull, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 

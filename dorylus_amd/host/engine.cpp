@@ -266,7 +266,10 @@ int dory_engine_run(dory_engine *e, uint32_t epochs, double *epoch_ms) {
     if (e->numNodes > 1) want_graph = 0;   // the exchange is not recorded
     if (e->recorded) {   // dory_preallocate / dory_graph_upload drop a recorded epoch behind the engine's back
         int64_t have = 0;
-        if (dory_get_option(e->eng->ctx, "epoch_graph_recorded", &have) || !have) e->recorded = false;
+        if (dory_get_option(e->eng->ctx, "epoch_graph_recorded", &have) || !have) {
+            e->recorded = false;
+            e->warmed = false;   // a new graph / tensor table: lazily sized buffers need one eager epoch again before recording
+        }
     }
     if (!want_graph && e->recorded) {
         dory_epoch_graph_drop(e->eng->ctx);

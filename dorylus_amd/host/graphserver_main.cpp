@@ -9,6 +9,7 @@
 // Node identity: --dshmachinesfile + --pripfile when both are readable (the reference's
 // way, nodemanager.cpp:290-311), else RANK / WORLD_SIZE / LOCAL_RANK from the environment
 // (torchrun / mpirun launchers), else a single node.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdarg>
@@ -84,6 +85,8 @@ static std::vector<std::string> read_lines(const std::string &path) {
     } while (0)
 
 int main(int argc, char **argv) {
+    struct timespec proc_start;
+    clock_gettime(CLOCK_REALTIME, &proc_start);   // id files older than this belong to another job
     auto args = parse_args(argc, argv);
     std::string datasetDir, featuresFile, layerFile, labelsFile, tmpDir = "/tmp", gnn = "GCN", s;
     if (args.count("help") || !lookup(args, "datasetdir", &datasetDir) || !lookup(args, "featuresfile", &featuresFile) ||
@@ -182,8 +185,9 @@ int main(int argc, char **argv) {
     CK(dory_weights_init_xavier(ctx));
     CK(dory_adam_config(ctx, lr));
     if (numNodes > 1) {  // RCCL bootstrap over a file in tmpdir (single node, shared filesystem)
-        // one id file per job: the launcher's rendezvous port (or DORY_JOB_ID) is the nonce, so a file left by a
-        // crashed run or written by a concurrent job is never mistaken for this job's id
+        // one id file per job: the launcher's rendezvous port (or DORY_JOB_ID) is the nonce that keeps concurrent jobs
+        // apart.  A file left behind by a crashed earlier job with the same nonce (MASTER_PORT is usually a constant)
+        // is older than this process: the other ranks only accept a file written after they started.
         const char *nonce = getenv("DORY_JOB_ID");
         if (!nonce || !*nonce) nonce = getenv("MASTER_PORT");
         const std::string idFile = tmpDir + "/dorylus_rccl_id." + (nonce && *nonce ? nonce : "default") + ".bin";
@@ -199,9 +203,14 @@ int main(int argc, char **argv) {
         } else {
             bool ok = false;
             for (int tries = 0; tries < 600 && !ok; ++tries) {
-                if (FILE *f = fopen(idFile.c_str(), "rb")) {
-                    ok = fread(id, 1, 128, f) == 128;
-                    fclose(f);
+                struct stat sb;
+                if (stat(idFile.c_str(), &sb) == 0 &&
+                    (sb.st_mtim.tv_sec > proc_start.tv_sec ||
+                     (sb.st_mtim.tv_sec == proc_start.tv_sec && sb.st_mtim.tv_nsec >= proc_start.tv_nsec))) {
+                    if (FILE *f = fopen(idFile.c_str(), "rb")) {
+                        ok = fread(id, 1, 128, f) == 128;
+                        fclose(f);
+                    }
                 }
                 if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }

@@ -210,9 +210,17 @@ int dory_ctx_describe(dory_ctx *ctx, int *gnn_type, uint32_t *num_layers, uint32
 int dory_timing_enable(dory_ctx *ctx, int on);
 int dory_timing_get(dory_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
 int dory_timing_reset(dory_ctx *ctx);
-/* tuning knobs (e.g. "spmm_variant", "spmm_slab"); unknown keys are an error */
+/* tuning knobs (e.g. "spmm_variant", "spmm_slab"); unknown keys are an error.  Read-only keys of dory_get_option:
+ * "spmm_gate_timeouts" (K1s sweeps whose workgroups were not co-resident within the polling bound: the launch and the
+ * context's next 16 K1s launches ran without gates -- same results, unsynchronised gather rate) and
+ * "spmm_ungated_launches"; "epoch_graph_recorded".  dory_timing_get("spmm_gate_timeouts") returns the same pair
+ * (launches = timeouts, total_ms = ungated launches). */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
+/* Diagnostic (no reference counterpart): hold `workgroups` whole CUs for `usec` microseconds with a sleeping kernel on
+ * the context's comm stream -- what an exchange's RCCL kernels or a co-tenant's kernels do to the aggregation that runs
+ * beside them.  Lets a single-GPU test exercise "spmm_sweep_reserve_cus" and the gate timeouts. */
+int dory_debug_occupy_cus(dory_ctx *ctx, uint32_t workgroups, uint64_t usec);
 
 /* Transform-first order of GCN layer 0 (option "gcn_transform_first" = 1; no reference counterpart): when the
  * input is wider than the first hidden layer, z0 = A (X W0) instead of (A X) W0, i.e. the aggregation gathers
@@ -235,6 +243,16 @@ int dory_transform_first_active(dory_ctx *ctx);
  * update of layer l follows that call.  dory_transform_first_active reports whether any layer is in this mode,
  * dory_transform_first_layer a particular one. */
 int dory_transform_first_layer(dory_ctx *ctx, uint32_t layer);
+
+/* Cached layer-0 aggregate (option "gcn_cache_ah0" = 1, default 0; no reference counterpart -- Engine::aggregateGCN
+ * recomputes A_hat x every epoch, gcn_ops.cpp:139-148, and so does the default here).  In full-graph training "ah"@0 is a
+ * constant of the run: "x" and "fg"@0 come from files and the adjacency never changes.  With the option on,
+ * dory_aggregate(0, DORY_FORWARD) returns at once while "ah"@0 still holds the aggregate of the current inputs: it is
+ * recomputed after any dory_tensor_upload / dory_tensor_fill_uniform / dory_halo_unpack* of a layer-0 tensor,
+ * dory_graph_upload, dory_preallocate or dory_set_option.  (A caller that writes "x" through the device pointer of
+ * dory_tensor_info must invalidate by one of those calls itself.)  Results are bit-identical to the uncached run: the
+ * same kernel produced the kept tensor.  Not combined with a recorded epoch (the recording always contains the
+ * aggregation).  dory_get_option "gcn_cache_ah0_skips" counts the aggregations answered from the kept tensor. */
 
 /* Epoch graph (MI355X-side addition, no reference counterpart): record the calls of one
  * epoch -- dory_aggregate / dory_apply_vertex / dory_apply_edge / dory_predict_gat /

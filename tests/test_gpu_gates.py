@@ -1,0 +1,101 @@
+"""K1s gates when their residency assumption is false.  A sweep = the G workgroups of an XCD that K1s keeps in step
+assumes G whole CUs per XCD; while dory_debug_occupy_cus holds 96 CUs with a sleeping kernel on the comm stream (what a
+co-tenant's kernel, or RCCL holding more CUs than reserved, does) fewer are there.  Required behaviour: results
+bit-identical to the unmasked run (placement is for speed only), the polling gives up within its bound, the timeout is
+COUNTED (dory_get_option "spmm_gate_timeouts" / "spmm_ungated_launches"), the context backs off -- later launches do
+not pay the timeout again -- and a context on a normal stream counts nothing."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(V, E, seed):
+    from helpers import random_graph
+    import partition_oracle as po
+    s, d = random_graph(seed, V, E)
+    return po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+
+
+def _ctx(da, g, V, F, stream=None):
+    ctx = da.Context(0)
+    ctx.configure(da.GCN, [F, 8, 4], V)
+    ctx.set_option("spmm_variant", 2)
+    ctx.set_option("spmm_blk_nb", 12)        # a graph this small would take K1: force the sweep over 12 source blocks
+    if stream is not None:
+        ctx.set_streams(compute=stream)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    ctx.fill_uniform(0, "x", 3)
+    return ctx
+
+
+@pytest.mark.timeout(300)
+def test_gate_timeouts_counted_and_results_unchanged_under_cu_mask():
+    import dorylus_amd as da
+    V, E, F = 60000, 1500000, 128
+    g = _graph(V, E, 5)
+    # reference run on the context's own stream: gates work, nothing is counted
+    ctx = _ctx(da, g, V, F)
+    for _ in range(3):
+        ctx.aggregate(0, da.FORWARD)
+    ref = ctx.download(0, "ah")
+    assert ctx.get_option("spmm_gate_timeouts") == 0 and ctx.get_option("spmm_ungated_launches") == 0
+    ctx.close()
+    # the same while a sleeping kernel holds 96 of the 256 CUs (12 per XCD) for the whole sequence
+    ctx = _ctx(da, g, V, F)
+    ctx.debug_occupy_cus(96, 400000)
+    time.sleep(0.01)
+    t0 = time.perf_counter()
+    ctx.aggregate(0, da.FORWARD)
+    timeouts = ctx.get_option("spmm_gate_timeouts")         # (synchronises the compute stream only; the occupier sleeps on)
+    first = time.perf_counter() - t0
+    assert timeouts >= 1                                    # the sweep's workgroups were not co-resident: counted
+    assert first < 0.1                                      # bounded polling (round 2: 20 000 polls ~ 0.1 s per gate)
+    t0 = time.perf_counter()
+    for _ in range(6):                                      # inside the back-off: no gates, no new timeouts
+        ctx.aggregate(0, da.FORWARD)
+    assert ctx.get_option("spmm_gate_timeouts") == timeouts
+    later = (time.perf_counter() - t0) / 6
+    assert ctx.get_option("spmm_ungated_launches") >= 6
+    assert later < first                                    # the timeout is not paid again on every launch
+    assert time.perf_counter() - t0 < 0.35                  # ... and all of it ran while the occupier held its CUs
+    assert np.array_equal(ctx.download(0, "ah"), ref)       # same bits whatever the placement (waits for the occupier)
+    tot_ms, n = ctx.timing_get("spmm_gate_timeouts")        # the same counters through dory_timing_get
+    assert n == timeouts and tot_ms >= 6
+    ctx.sync()                                              # the occupier is gone
+    for _ in range(20):                                     # past the back-off horizon the gates are tried again and hold
+        ctx.aggregate(0, da.FORWARD)
+    assert np.array_equal(ctx.download(0, "ah"), ref)
+    assert ctx.get_option("spmm_gate_timeouts") == timeouts
+    assert ctx.get_option("spmm_ungated_launches") <= 17
+    ctx.close()
+
+
+def test_sweep_knobs_are_per_context():
+    """spmm_sweep_rows / spmm_sweep_pair were process-wide in round 2: a second context must not inherit them."""
+    import dorylus_amd as da
+    V, E, F = 20000, 400000, 128
+    g = _graph(V, E, 6)
+    a = _ctx(da, g, V, F)
+    a.aggregate(0, da.FORWARD)
+    ref = a.download(0, "ah")
+    b = da.Context(0)
+    b.configure(da.GCN, [F, 8, 4], V)
+    b.set_option("spmm_variant", 2)
+    b.set_option("spmm_blk_nb", 12)
+    b.set_option("spmm_sweep_rows", 4)
+    b.set_option("spmm_sweep_pair", 1)
+    b.graph_upload(g)
+    b.preallocate()
+    b.fill_uniform(0, "x", 3)
+    b.aggregate(0, da.FORWARD)
+    from helpers import rel_err
+    assert rel_err(b.download(0, "ah"), ref) < 1e-5         # another deal of the rows: same sums to reassociation
+    assert a.get_option("spmm_sweep_rows") == 0 and a.get_option("spmm_sweep_pair") == -1
+    a.aggregate(0, da.FORWARD)
+    assert np.array_equal(a.download(0, "ah"), ref)         # context a still runs its own layout
+    a.close()
+    b.close()

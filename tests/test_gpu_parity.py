@@ -706,6 +706,66 @@ def test_gcn_numpy_gnn_fixture_backward_half_baseline_widths(da, golden_dir, nam
         ctx.close()
 
 
+def test_gcn_cache_ah0_bit_identical_and_invalidated(da):
+    """Opt-in gcn_cache_ah0: three learning epochs with and without the kept layer-0 aggregate give the same bits in
+    ah0, z0, every dW and every weight; re-uploading x (or refilling fg@0, or touching an option) recomputes."""
+    from helpers import random_graph
+    V, P, dims = 3000, 2, [96, 32, 6]
+    s, d = random_graph(33, V, 40000)
+    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+    part = da.Partition.build(s, d, parts, 0, P)                 # rank 0 of 2: ghost rows in fg@0 as well
+    g = part.view()
+    N = int(g["localVtxCnt"])
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, (N, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], N).astype(np.uint32)
+    res = {}
+    for cache in (0, 1):
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, dims, V)
+        ctx.set_option("spmm_blk_nb", 8)
+        part.upload(ctx)
+        ctx.preallocate()
+        ctx.upload(0, "x", X)
+        ctx.fill_uniform(0, "fg", 9, -1.0, 1.0, g["srcGhost"])
+        ctx.labels_upload(labels)
+        ctx.weights_init_xavier()
+        ctx.adam_config(0.01)
+        ctx.set_option("gcn_cache_ah0", cache)
+        eng = da.NativeEngine(ctx)
+        out = []
+        for _ in range(3):
+            eng.run(1)
+            out.append([ctx.download(0, "ah"), ctx.download(0, "z"), ctx.weight_grad_get(0), ctx.weight_grad_get(1),
+                        ctx.weight_get(0), ctx.weight_get(1)])
+        assert ctx.get_option("gcn_cache_ah0_skips") == (2 if cache else 0)
+        if cache:
+            # invalidation: new x -> recomputed (equals a fresh aggregate), and kept again afterwards
+            X2 = (X * np.float32(0.5)).astype(np.float32)
+            ctx.upload(0, "x", X2)
+            skips = ctx.get_option("gcn_cache_ah0_skips")
+            ctx.aggregate(0, da.FORWARD)
+            assert ctx.get_option("gcn_cache_ah0_skips") == skips
+            a2 = ctx.download(0, "ah")
+            ctx.set_option("gcn_cache_ah0", 0)
+            ctx.aggregate(0, da.FORWARD)
+            assert np.array_equal(ctx.download(0, "ah"), a2) and not np.array_equal(a2, out[0][0])
+            ctx.set_option("gcn_cache_ah0", 1)
+            ctx.aggregate(0, da.FORWARD)                          # (set_option invalidated: computes)
+            ctx.aggregate(0, da.FORWARD)                          # kept
+            assert ctx.get_option("gcn_cache_ah0_skips") == skips + 1
+            ctx.fill_uniform(0, "fg", 10, -1.0, 1.0, g["srcGhost"])
+            ctx.aggregate(0, da.FORWARD)                          # ghost rows changed: computes
+            assert ctx.get_option("gcn_cache_ah0_skips") == skips + 1
+            assert not np.array_equal(ctx.download(0, "ah"), a2)
+        res[cache] = out
+        eng.close()
+        ctx.close()
+    for ep in range(3):
+        for a, b in zip(res[0][ep], res[1][ep]):
+            assert np.array_equal(a, b), ep
+
+
 def test_adam_and_xavier_vs_oracle(da):
     import orc
     import partition_oracle as po
