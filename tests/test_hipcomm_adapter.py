@@ -33,6 +33,13 @@ def test_hipcomm_adapter_parses_against_reference_headers(tmp_path):
            os.path.join(ROOT, "tests", "hipcomm_adapter.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-4000:]
+    # the multi-node wiring is really there (round 2 computed the plan and threw it away): plan, communicator, and the
+    # weight-server variant over the wire formats
+    src = open(os.path.join(ROOT, "tests", "hipcomm_adapter.cpp")).read()
+    for call in ("dory_halo_plan(", "dory_comm_unique_id(", "dory_comm_init(", "dory_weight_grad_get(", "dory_wire_build_push(",
+                 "dory_wire_build_pull(", "dory_wire_parse_pull_reply(", "dory_weight_set(", "controlPushOut(", "controlPullIn("):
+        assert call in src, call
+    assert "(void)" not in src
     # the contract the adapter relies on is still what the reference declares
     rc = open(os.path.join(REF, "graph-server", "commmanager", "resource_comm.hpp")).read()
     assert "virtual void NNCompute(Chunk &chunk) = 0;" in rc and "void NNRecvCallback(Engine *engine, Chunk &chunk);" in rc
