@@ -47,7 +47,7 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     bool &built = csc ? c->swpIn_built : c->swpOut_built;
     bool &na = csc ? c->swpIn_na : c->swpOut_na;
     const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
-    if (built && (csc ? c->swpIn_want_nb : c->swpOut_want_nb) != want_nb && !c->capturing) {     // another block count requested (tests): rebuild
+    if (built && (csc ? c->swpIn_want_nb : c->swpOut_want_nb) != want_nb && !c->capturing) {   // another block count requested (tests): rebuild
         HIPCK(c, hipStreamSynchronize(c->compute));
         free_blocked(&S);
         built = false;

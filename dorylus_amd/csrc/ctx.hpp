@@ -227,7 +227,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
                                BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */,
                                uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */);
-int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r = 0 /* option spmm_sweep_rows: 0 = by fill */);
+int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r = 0 /* option spmm_sweep_rows: 0 = by fill */, int max_r = 10);
 // host/sweep_deal.cpp: rows per lane group of the K1s layout and the position of every (sorted) item
 bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos);
 bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);

@@ -801,6 +801,65 @@ struct SweepArgs {
     uint32_t seq;        // launch number of the context
 };
 
+// ---- the gate and the arrival, shared by the sweep kernels ------------------------------------------------------------
+// gate: step sb may start once every workgroup of the sweep has finished step sb - SWEEP_SLACK - 1 (for the first steps:
+// of the previous sweep of this XCD).  *lds_allowed = number of steps this workgroup may start.
+__device__ __forceinline__ void sweep_gate(const SweepArgs &w, bool gated, uint32_t sb, uint32_t q, uint32_t nbs, uint32_t *dq,
+                                           uint32_t cnt_q, uint32_t cnt_p, uint32_t *gates_off, uint32_t *lds_allowed,
+                                           uint32_t *lds_lock, int lane) {
+    const int bb = (int)sb - SWEEP_SLACK - 1;
+    const bool prev = bb < 0;
+    const uint32_t *word = !prev ? dq + (size_t)bb * 32
+                                 : (q > 0 && (int)nbs + bb >= 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
+    const uint32_t need = !prev ? cnt_q : cnt_p;
+    if (word && lane == 0 && gated) {
+        const uint32_t limit = prev ? SWEEP_SPIN_SHORT + SWEEP_SPIN_PER_STEP * nbs : SWEEP_SPIN_SHORT;
+        while (__hip_atomic_load(lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
+            if (__hip_atomic_exchange(lds_lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                uint32_t spins = 0;      // this wave polls for the workgroup
+                while (__hip_atomic_load(lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; i += 4) {
+                        u4 v;
+                        const uint32_t *p = word + i;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+                        sum += v.x + v.y + v.z + v.w;
+                    }
+                    if (sum >= need || __hip_atomic_load(gates_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > limit) {
+                        // the sweep's workgroups are not co-resident (or not on this XCD): the rest of this launch
+                        // and the context's next SWEEP_BACKOFF launches run ungated -- same results, counted
+                        if (__hip_atomic_exchange(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                            __hip_atomic_fetch_add(w.stat + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_max(w.stat + 1, w.seq + 1u + SWEEP_BACKOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        break;
+                    }
+                }
+                // (a wave at a later step may have raised it meanwhile: never lower it)
+                __hip_atomic_fetch_max(lds_allowed, sb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(lds_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+}
+
+// the last wave of a workgroup to finish step sb reports it in the workgroup's own word of the (sweep, step) line
+__device__ __forceinline__ void sweep_arrive(uint32_t sb, uint32_t t, uint32_t *dq, uint32_t *lds_cnt, int lane, int nwaves) {
+    if (lane == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == (uint32_t)nwaves - 1) {
+            __hip_atomic_store(&lds_cnt[sb & 7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dq + (size_t)sb * 32 + (t & 31), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 template <int GROUP, int R, bool UNIT, bool PAIR>
 __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
                                                               SweepArgs w) {
@@ -890,49 +949,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
 
     for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
         const uint32_t sb = b - w.b_lo;                      // step of this launch
-        {   // gate: step sb may start once every workgroup of the sweep has finished step sb - SWEEP_SLACK - 1 (for the
-            // first steps: of the previous sweep of this XCD).  lds_allowed = number of steps this workgroup may start.
-            const int bb = (int)sb - SWEEP_SLACK - 1;
-            const bool prev = bb < 0;
-            const uint32_t *word = !prev ? dq + (size_t)bb * 32
-                                         : (q > 0 && (int)nbs + bb >= 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
-            const uint32_t need = !prev ? cnt_q : cnt_p;
-            if (word && lane == 0 && gated) {
-                const uint32_t limit = prev ? SWEEP_SPIN_SHORT + SWEEP_SPIN_PER_STEP * nbs : SWEEP_SPIN_SHORT;
-                while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
-                    if (__hip_atomic_exchange(&lds_lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-                        uint32_t spins = 0;      // this wave polls for the workgroup
-                        while (__hip_atomic_load(&lds_allowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sb) {
-                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                            uint32_t sum = 0;
-#pragma unroll
-                            for (int i = 0; i < 32; i += 4) {
-                                u4 v;
-                                const uint32_t *p = word + i;
-                                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-                                sum += v.x + v.y + v.z + v.w;
-                            }
-                            if (sum >= need || __hip_atomic_load(gates_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                            __builtin_amdgcn_s_sleep(4);
-                            if (++spins > limit) {
-                                // the sweep's workgroups are not co-resident (or not on this XCD): the rest of this launch
-                                // and the context's next SWEEP_BACKOFF launches run ungated -- same results, counted
-                                if (__hip_atomic_exchange(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                                    __hip_atomic_fetch_add(w.stat + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_fetch_max(w.stat + 1, w.seq + 1u + SWEEP_BACKOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                                break;
-                            }
-                        }
-                        // (a wave at a later step may have raised it meanwhile: never lower it)
-                        __hip_atomic_fetch_max(&lds_allowed, sb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(&lds_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-            }
-        }
+        sweep_gate(w, gated, sb, q, nbs, dq, cnt_q, cnt_p, gates_off, &lds_allowed, &lds_lock, lane);
         // offsets of the next step (in flight during this one)
         uint32_t my_o_next = 0;
         if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (B.npos + 1))[orow];
@@ -1020,13 +1037,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         my_o = my_o_next;
         if (b + 1 < w.b_hi)
             load_entries(B.bbase[b + 1], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
-        if (lane == 0) {   // the last wave to finish the step reports it for the workgroup
-            const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == NW - 1) {
-                __hip_atomic_store(&lds_cnt[sb & 7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(dq + (size_t)sb * 32 + (t & 31), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        sweep_arrive(sb, t, dq, lds_cnt, lane, NW);
     }
 
     // one store path for rows and for pieces of split rows (a piece: the bare sum into its slot, no scale, no self
@@ -1272,14 +1283,14 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 
 // rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab;
 // force_r (option spmm_sweep_rows of the context; tests, experiments): 0 = pick by fill
-int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r) {
-    if (force_r == 2 || force_r == 4 || force_r == 6 || force_r == 8 || (force_r == 10 && group == 32))
+int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r, int max_r) {
+    if (force_r == 2 || force_r == 4 || force_r == 6 || force_r == 8 || (force_r == 10 && group == 32 && max_r >= 10))
         return force_r;
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
     double best_fill = 0;
     for (int R : {10, 8, 6, 4, 2}) {            // few rows per group: small partitions (one of 8 ranks) still fill every CU
-        if (group == 16 && R == 10) continue;   // 16-lane groups stage twice the entries per lane: 10 rows would spill
+        if ((group == 16 && R == 10) || R > max_r) continue;   // 16-lane groups stage twice the entries per lane: 10 rows would spill
         const uint32_t RW = (uint32_t)(SWEEP_NT / group) * R;
         const uint32_t tiles = (rpx + RW - 1) / RW;
         const uint32_t spp = (tiles + G - 1) / G;
@@ -1300,10 +1311,10 @@ bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
 // rows per lane group of a launch: what the layout was dealt for, unless forced (option) or not instantiated for the
 // lane-group width
 static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G, int force_r) {
-    const int forced = sweep_pick_r(0, group, G, force_r);      // (returns the forced value whatever N when one is valid)
+    const int forced = sweep_pick_r(0, group, G, force_r, 10);      // (returns the forced value whatever N when one is valid)
     if (force_r && forced == force_r) return forced;
     if (B.rows_per_group && (group == 32 || B.rows_per_group <= 8)) return (int)B.rows_per_group;
-    return sweep_pick_r(B.npos, group, G, 0);
+    return sweep_pick_r(B.npos, group, G, 0, 10);
 }
 
 // counter words one launch over nblocks source blocks needs (callers size the scratch for the largest launch)
