@@ -51,9 +51,9 @@ def synth_edges(kind, V, E, seed=42):
         s = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
         d = perm[np.minimum((rng.random(half) ** 1.5 * V).astype(np.int64), V - 1)]
     elif kind == "rmat":
-        # R-MAT, a=.57 b=.19 c=.19 d=.05, 18 levels (2^18 >= V; ids folded back with mod V), ids shuffled.
-        # Far more skewed than real Reddit: the top vertices carry ~1 % of all endpoints each.
-        levels = 18
+        # R-MAT, a=.57 b=.19 c=.19 d=.05, ceil(log2 V) levels (18 at Reddit scale; ids folded back with
+        # mod V), ids shuffled.  Far more skewed than real Reddit: the top vertices carry ~1 % of all endpoints each.
+        levels = max(1, int(np.ceil(np.log2(V))))
         s = np.zeros(half, np.uint32)
         d = np.zeros(half, np.uint32)
         for _ in range(levels):
@@ -477,6 +477,22 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what):
     res = {"what": what, "ms_per_step": ms, "steps": steps, "warmup": warmup, "edges_per_s": edges / (ms * 1e-3),
            "spmm_variant": ctx.get_option("spmm_variant"),
            "kernel_ms_per_epoch": {k: round(v[0] / steps, 4) for k, v in fam.items() if v[1]}}
+    if gnn == "gatmh" and fam["spmm"][1]:
+        # compulsory bytes of the epoch's six edge passes (forward, destination-side and source-side backward sweeps of both
+        # layers: 4 over the CSC, 2 over the CSR), each: the index stream once + pointers + one read and one write of an
+        # N x ld row tensor (z / dO in, o / dz out; the per-(vertex, head) scores and statistics are K floats per row)
+        lds = [(DIMS[1] + 31) // 32 * 32, (DIMS[2] + 31) // 32 * 32]
+        algo = 0
+        for ld_, K_ in ((lds[0], 8), (lds[1], 1)):
+            for nnz in (nnz_in, nnz_in, nnz_out):
+                algo += 4 * nnz + 8 * (N + 1) + 2 * 4 * N * ld_ + 4 * 4 * N * K_
+        t = fam["spmm"][0] / steps * 1e-3
+        res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": None,
+                           "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
+                           "kernel": "gatmh_*_blocked_kernel family + reduce kernels (six edge passes per epoch)",
+                           "gathered_bytes_per_epoch": int(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) ),
+                           "l1_path_frac": round(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) / t / 1e12 / 37.7, 4)}
     eng.close()
     ctx.close()
     return res
