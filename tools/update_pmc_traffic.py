@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Refresh profiles/pmc_traffic.json's K1s entry from a tools/collect_profiles.sh run and stamp it with the git blob hash of
+the kernel source it was collected for (bench.py reports `traffic: null` when the stamp and the built source disagree).
+  python tools/update_pmc_traffic.py r03b        # reads profiles/<tag>_pmc_fetch_size.txt / _write_size.txt"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import git_blob_sha1  # noqa: E402
+
+
+def counter_sum(path, counter, pattern):
+    tot, names = 0.0, []
+    for line in open(path):
+        m = re.match(r"(.*?)\s+" + counter + r"\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+        if m and re.search(pattern, m.group(1)):
+            tot += float(m.group(3))
+            names.append(m.group(1).strip()[:60])
+    return tot, names
+
+
+def main():
+    tag = sys.argv[1]
+    f = os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt")
+    w = os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt")
+    fetch, names = counter_sum(f, "FETCH_SIZE", r"spmm_sweep_kernel|spmm_sweep_combine")
+    write, _ = counter_sum(w, "WRITE_SIZE", r"spmm_sweep_kernel|spmm_sweep_combine")
+    launches = 3   # the epoch's aggregations: F=602 forward, F=128 forward, F=128 backward (bench.py --steps 1 --warmup 0)
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pm = json.load(open(p))
+    pm["spmm_variant_2"] = {
+        "kernels": "spmm_sweep_kernel<32,10,false,PAIR> (K1s; PAIR on for the five-slab F=602 launch, off for the single-slab F=128 launches)",
+        "fetch_size_kb_avg": round(fetch / launches, 1), "write_size_kb_avg": round(write / launches, 1),
+        "bytes_per_launch": int((2 * fetch + write) / launches * 1024),
+        "source": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt"],
+        "spmm_hip_blob": git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip")),
+        "note": "tools/collect_profiles.sh + tools/update_pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-alt`, summed over the sweep kernels of the epoch / 3 launches; "
+                "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported.  Round 2 (r02e): 10.445 GB",
+    }
+    json.dump(pm, open(p, "w"), indent=2)
+    print(pm["spmm_variant_2"]["bytes_per_launch"], names)
+
+
+if __name__ == "__main__":
+    main()
