@@ -160,6 +160,8 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
     c->opt["spmm_sweep_rows"] = 0;           // K1s: rows per lane group, 0 = by fill (2/4/6/8/10; tests and experiments)
     c->opt["spmm_sweep_pair"] = -1;          // K1s: two rows of a lane group as one stream of entries: -1 = launches of >= 3 slabs, 0 = never, 1 = always
+    c->opt["spmm_sweep_loader"] = 1;         // K1s, 32-lane launches: wave 0 of a workgroup copies the next step's entries and offsets into LDS for all sixteen
+    c->opt["spmm_sweep_loader_relief"] = 3;  // ... and the layout gives each of its two lane groups this many rows fewer per sweep (set before the layout is built)
     c->opt["spmm_sweep_reserve_cus"] = 4;    // K1s under an exchange in flight: CUs per XCD its sweeps leave to the RCCL kernels
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)

@@ -68,7 +68,8 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);   // the deal is made for the 32-lane launches
     HIPCK(c, build_blocked_sweep(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal, c->N,
                                  NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, window, R, &S, c->compute,
-                                 (uint32_t)c->opt["spmm_sweep_layout"], std::min<uint32_t>(32u, c->cus_per_xcd)));
+                                 (uint32_t)c->opt["spmm_sweep_layout"], std::min<uint32_t>(32u, c->cus_per_xcd),
+                                 group == 32 && c->opt["spmm_sweep_loader"] ? (uint32_t)c->opt["spmm_sweep_loader_relief"] : 0u));
     (csc ? c->swpIn_want_nb : c->swpOut_want_nb) = want_nb;
     built = true;
     return DORY_OK;
@@ -130,6 +131,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             ctl.force_r = force_r;
             ctl.pair = (int)c->opt["spmm_sweep_pair"];
             ctl.stat = c->sweep_stat;
+            ctl.loader = c->opt["spmm_sweep_loader"] != 0;
             SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
             if (two) {
                 // under an exchange in flight the RCCL kernels need CUs of their own

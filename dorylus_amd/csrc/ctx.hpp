@@ -226,16 +226,18 @@ void free_blocked(BlockedAdj *B);
 hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
                                BlockedAdj *out, hipStream_t s, uint32_t layout = 3 /* 1: spread sources, 2: deal rows by degree */,
-                               uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */);
+                               uint32_t sweep_tiles = 32 /* workgroups per sweep and XCD the deal is made for */,
+                               uint32_t loader_relief = 0 /* rows per sweep kept off the two lane groups of every workgroup's wave 0 */);
 int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r = 0 /* option spmm_sweep_rows: 0 = by fill */, int max_r = 10);
 // host/sweep_deal.cpp: rows per lane group of the K1s layout and the position of every (sorted) item
-bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos);
+bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos, uint32_t loader_relief = 0);
 bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 // per-context knobs and state of the K1s launches (nothing process-wide)
 struct SweepCtl {
     int force_r = 0;            // option spmm_sweep_rows
     int pair = -1;              // option spmm_sweep_pair
+    bool loader = true;         // option spmm_sweep_loader: wave 0 of a workgroup copies the next step's entries for all (32-lane launches)
     uint32_t *stat = nullptr;   // 4 device words that outlive the launches: gate timeouts, launch number that gates again,
                                 // ungated launches, spare
     uint32_t seq = 0;           // launch number

@@ -850,17 +850,26 @@ __device__ __forceinline__ void sweep_gate(const SweepArgs &w, bool gated, uint3
 }
 
 // the last wave of a workgroup to finish step sb reports it in the workgroup's own word of the (sweep, step) line
-__device__ __forceinline__ void sweep_arrive(uint32_t sb, uint32_t t, uint32_t *dq, uint32_t *lds_cnt, int lane, int nwaves) {
+__device__ __forceinline__ void sweep_arrive(uint32_t sb, uint32_t t, uint32_t *dq, uint32_t *lds_cnt, int lane, int nwaves,
+                                             uint32_t *lds_wgdone = nullptr /* LOADER: steps every wave of the workgroup has finished */) {
     if (lane == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t old = __hip_atomic_fetch_add(&lds_cnt[sb & 7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (old == (uint32_t)nwaves - 1) {
             __hip_atomic_store(&lds_cnt[sb & 7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lds_wgdone) __hip_atomic_store(lds_wgdone, sb + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(dq + (size_t)sb * 32 + (t & 31), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
 
-template <int GROUP, int R, bool UNIT, bool PAIR>
+// LOADER (32-lane groups): wave 0 of the workgroup copies every lane group's entries and the workgroup's row offsets of
+// the NEXT step into LDS (LDS-DMA, three buffers) while all sixteen waves work on this one.  Why: a wave's vector loads
+// return in order, so a wave that requests its own entries -- they stream from HBM, 2-3 us -- cannot get its next gathers
+// back before them: 8-11 % of a launch with the gates on (profiles/r03_experiments.txt items 4, 9).  The wait is per
+// wave: taken by one wave (whose lane groups the layout deals fewer rows, SWEEP_LOADER_RELIEF) it is off the path of the
+// other fifteen, which issue nothing but gathers.
+
+template <int GROUP, int R, bool UNIT, bool PAIR, bool LOADER>
 __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
                                                               SweepArgs w) {
     constexpr int GPW = 64 / GROUP;
@@ -868,12 +877,18 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     constexpr int NW = SWEEP_NT / 64;
     constexpr int RW = NGRP * R;
     constexpr int C = SWEEP_C, U = SWEEP_U, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
-    __shared__ uint2 stage[NGRP][C];
-    __shared__ uint32_t o_lds[NGRP][R + 2];
-    __shared__ uint32_t lds_allowed, lds_lock, lds_cnt[8];
+    constexpr int NBUF = LOADER ? 3 : 1;
+    constexpr int OFFB = (RW + 1 + 63) / 64 * 64;           // LOADER: the block's base (lo, hi) sits behind the copied offsets
+    static_assert(!LOADER || (GROUP == 32 && C == 128), "the loader copies one 1 KB slot per lane group and instruction");
+    __shared__ uint2 stage[NBUF * NGRP][C];
+    __shared__ uint32_t o_lds[LOADER ? 1 : NGRP][R + 2];
+    __shared__ uint32_t offl[LOADER ? NBUF : 1][LOADER ? OFFB + 2 : 1];
+    __shared__ uint32_t lds_allowed, lds_lock, lds_cnt[8], lds_ready, lds_wgdone;
     if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 8) lds_allowed = 0;
     if (threadIdx.x == 9) lds_lock = 0;
+    if (threadIdx.x == 10) lds_ready = 0;
+    if (threadIdx.x == 11) lds_wgdone = 0;
     __syncthreads();
     const uint32_t id = blockIdx.x, xcd = id & 7u, k = id >> 3;
     const uint32_t spp = (w.tiles_x + w.G - 1) / w.G;        // sweeps per slab
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const bool gated = !(w.flags & 8u) && !(w.seq < __hip_atomic_load(w.stat + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (!gated && blockIdx.x == 0 && threadIdx.x == 0 && !(w.flags & 8u))
         __hip_atomic_fetch_add(w.stat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane % GROUP, gi = lane / GROUP;
     const int g = wave * GPW + gi;
     const uint32_t xend = min((xcd + 1) * w.rpx, B.npos);   // positions (= rows without B.perm)
@@ -901,7 +916,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     const uint32_t ccol = col_ok ? col : 0;
     const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl) + ccol;
     uint2 *st = stage[g];
-    uint32_t *ol = o_lds[g];
+    const uint32_t *ol = LOADER ? offl[0] : o_lds[g];
     const uint32_t orow = min(v0 + (uint32_t)min(li, R), xend);   // lane li <= R holds the offset of row v0 + li
 
     float4 acc[R];
@@ -943,23 +958,98 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         }
     };
 
-    uint32_t my_o = (B.boff + (size_t)w.b_lo * (B.npos + 1))[orow];
+    uint32_t my_o = 0;
     u4 en_pre[CQ];
-    load_entries(B.bbase[w.b_lo], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
+    // ---- LOADER: the copies of one step, issued by wave 0 ----
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const uint32_t pos0 = xcd * w.rpx + t * RW;              // first position of the workgroup
+    // lane j < NGRP of wave 0: first offset of lane group j in step `stp` (the addresses of the entry copies come out of
+    // a register: a load between two copies would have to wait for the first)
+    auto group_starts = [&](uint32_t stp) -> uint32_t {
+        return stp < nbs ? (B.boff + (size_t)(w.b_lo + stp) * (B.npos + 1))[min(pos0 + (uint32_t)min(lane, NGRP - 1) * R, xend)] : 0u;
+    };
+    auto block_base = [&](uint32_t stp) -> uint64_t { return stp < nbs ? B.bbase[w.b_lo + stp] : 0ull; };
+    auto copy_step = [&](uint32_t stp, uint32_t gstart, uint64_t base) {
+        const uint32_t bs = w.b_lo + stp, buf = stp % (uint32_t)NBUF;
+        if constexpr (LOADER)
+            if (lane == 0) { offl[buf][OFFB] = (uint32_t)base; offl[buf][OFFB + 1] = (uint32_t)(base >> 32); }
+        const uint32_t *orow_b = B.boff + (size_t)bs * (B.npos + 1);
+#pragma unroll
+        for (int j = 0; j < OFFB / 64; ++j)                  // the RW + 1 row offsets of the workgroup's positions
+            if ((uint32_t)(j * 64 + lane) <= (uint32_t)RW)
+                __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)(j * 64 + lane), xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, 0);
+#pragma unroll
+        for (int gg = 0; gg < NGRP; ++gg) {                  // one 1 KB run of entries per lane group, from the even entry at or before its first
+            const uint64_t A0 = (base + (uint32_t)__builtin_amdgcn_readlane((int)gstart, gg)) & ~1ull;
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + lane), (lptr_t)&stage[buf * NGRP + gg][0], 16, 0, 0);
+        }
+    };
+    auto uniform64 = [&](uint64_t v) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    // the loader's look-ahead: the lane groups' first offsets and the block base of the step after the one being copied
+    // (requested behind the copies, back with them)
+    uint32_t gs_next = 0;
+    uint64_t bb_next = 0;
+    if constexpr (LOADER) {
+        if (wave == 0) {
+            const uint32_t gs0 = group_starts(0);
+            const uint64_t bb0 = uniform64(block_base(0));
+            copy_step(0, gs0, bb0);
+            gs_next = group_starts(1);
+            bb_next = block_base(1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the copies have landed
+            bb_next = uniform64(bb_next);
+            if (lane == 0) __hip_atomic_store(&lds_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        my_o = (B.boff + (size_t)w.b_lo * (B.npos + 1))[orow];
+        load_entries(B.bbase[w.b_lo], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
+    }
 
     for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
         const uint32_t sb = b - w.b_lo;                      // step of this launch
         sweep_gate(w, gated, sb, q, nbs, dq, cnt_q, cnt_p, gates_off, &lds_allowed, &lds_lock, lane);
-        // offsets of the next step (in flight during this one)
-        uint32_t my_o_next = 0;
-        if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (B.npos + 1))[orow];
-        if (li <= R) ol[li] = my_o;
-        const uint32_t o0 = (uint32_t)__shfl((int)my_o, 0, GROUP), oR = (uint32_t)__shfl((int)my_o, R, GROUP);
-        const uint64_t base = B.bbase[b];
+        uint32_t my_o_next = 0, o0, oR;
+        uint64_t base;
+        if constexpr (LOADER) {
+            if (wave == 0 && sb + 1 < nbs) {
+                // the buffer of step sb + 1 was last read in step sb - 2: every wave must be past it
+                if (sb >= 2)
+                    while (__hip_atomic_load(&lds_wgdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sb - 1u) __builtin_amdgcn_s_sleep(2);
+                copy_step(sb + 1, gs_next, bb_next);
+                gs_next = group_starts(sb + 2);
+                bb_next = block_base(sb + 2);
+                __builtin_amdgcn_s_waitcnt(0x0f70);          // the one in-order wait of the workgroup, taken here
+                bb_next = uniform64(bb_next);
+                if (lane == 0) __hip_atomic_store(&lds_ready, sb + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            while (__hip_atomic_load(&lds_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sb + 1u) __builtin_amdgcn_s_sleep(1);
+            const uint32_t buf = sb % (uint32_t)NBUF;
+            ol = &offl[buf][g * R];
+            o0 = ol[0]; oR = ol[R];
+            base = ((uint64_t)offl[buf][OFFB + 1] << 32) | offl[buf][OFFB];
+            st = &stage[buf * NGRP + g][0] + (uint32_t)((base + o0) & 1ull);   // entry e of the first pass sits at slot e - o0 + (the copy began one entry early)
+        } else {
+            // offsets of the next step (in flight during this one)
+            if (b + 1 < w.b_hi) my_o_next = (B.boff + (size_t)(b + 1) * (B.npos + 1))[orow];
+            if (li <= R) o_lds[g][li] = my_o;
+            o0 = (uint32_t)__shfl((int)my_o, 0, GROUP); oR = (uint32_t)__shfl((int)my_o, R, GROUP);
+            base = B.bbase[b];
+        }
         for (uint32_t cs = o0; cs < oR; cs += CE) {
             const uint32_t ce = min(cs + CE, oR);
-            if (cs != o0) load_entries(base, cs, oR, en_pre);      // (rare: more than CE entries of the group in one step)
-            stage_entries(base, cs, ce, en_pre);
+            if constexpr (LOADER) {
+                if (cs != o0) {   // (rare: more than CE entries of the group in one step) the group fetches the rest itself
+                    st = &stage[(sb % (uint32_t)NBUF) * NGRP + g][0];
+                    load_entries(base, cs, oR, en_pre);
+                    stage_entries(base, cs, ce, en_pre);
+                }
+            } else {
+                if (cs != o0) load_entries(base, cs, oR, en_pre);      // (rare: more than CE entries of the group in one step)
+                stage_entries(base, cs, ce, en_pre);
+            }
             if constexpr (PAIR) {
             // two consecutive rows of a lane group as one stream of entries: one tail per two rows, and the two lane
             // groups of a wave differ less over 20 entries than over 10; an entry goes to the first or the second row's
@@ -1033,11 +1123,13 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
             }
             }
         }
-        // first pass of the next step's entries: in flight across the gate
-        my_o = my_o_next;
-        if (b + 1 < w.b_hi)
-            load_entries(B.bbase[b + 1], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
-        sweep_arrive(sb, t, dq, lds_cnt, lane, NW);
+        if constexpr (!LOADER) {
+            // first pass of the next step's entries: in flight across the gate
+            my_o = my_o_next;
+            if (b + 1 < w.b_hi)
+                load_entries(B.bbase[b + 1], (uint32_t)__shfl((int)my_o, 0, GROUP), (uint32_t)__shfl((int)my_o, R, GROUP), en_pre);
+        }
+        sweep_arrive(sb, t, dq, lds_cnt, lane, NW, LOADER ? &lds_wgdone : nullptr);
     }
 
     // one store path for rows and for pieces of split rows (a piece: the bare sum into its slot, no scale, no self
@@ -1143,7 +1235,7 @@ constexpr uint32_t SWEEP_SPLIT = 2;
 
 hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const float *val, uint32_t N, uint32_t NG,
                                uint64_t nnz, uint32_t want_nb, uint32_t row_bytes, uint64_t window_bytes, int R,
-                               BlockedAdj *out, hipStream_t s, uint32_t layout, uint32_t sweep_tiles) {
+                               BlockedAdj *out, hipStream_t s, uint32_t layout, uint32_t sweep_tiles, uint32_t loader_relief) {
     BlockedAdj B{};
     if (N == 0 || NG == 0) { *out = B; return hipSuccess; }
     hipError_t e;
@@ -1181,7 +1273,7 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     std::vector<uint32_t> ipos(nl);
     if (layout & 2u) {
         std::vector<uint32_t> cap;
-        if (!sweep_deal_plan(nl, (uint32_t)R, sweep_tiles, &cap, &npos) || !sweep_deal_positions(nl, (uint32_t)R, cap, ipos.data()))
+        if (!sweep_deal_plan(nl, (uint32_t)R, sweep_tiles, &cap, &npos, loader_relief) || !sweep_deal_positions(nl, (uint32_t)R, cap, ipos.data()))
             return hipErrorInvalidValue;
     } else {
         for (uint32_t i = 0; i < nl; ++i) ipos[i] = i;
@@ -1256,8 +1348,9 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     BCK(hipMemsetAsync(cnt, 0, (size_t)nb * npos * sizeof(uint32_t), s));
     BCK(hipMalloc((void **)&B.boff, (size_t)nb * (npos + 1) * sizeof(uint32_t)));
     BCK(hipMalloc((void **)&B.bbase, (size_t)(nb + 1) * sizeof(uint64_t)));
-    BCK(hipMalloc((void **)&B.bent, (nnz + 2) * sizeof(uint2)));
-    BCK(hipMemsetAsync(B.bent + nnz, 0, 2 * sizeof(uint2), s));
+    // (the loader copies whole 1 KB runs: up to 128 entries past a lane group's last one are read, never used)
+    BCK(hipMalloc((void **)&B.bent, (nnz + 130) * sizeof(uint2)));
+    BCK(hipMemsetAsync(B.bent + nnz, 0, 130 * sizeof(uint2), s));
     BCK(hipMalloc((void **)&dtotal, nb * sizeof(uint64_t)));
     hipLaunchKernelGGL(blk_count_kernel, dim3((npos + 255) / 256), dim3(256), 0, s, npos, ptr, idx, B.SB, cnt, B.perm, d_sblk,
                        (const uint2 *)d_slice);
@@ -1363,12 +1456,16 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     // 13.3 ms; four: 11.0 -> 10.8; three: 8.16 -> 8.1), not on one or two (F=128: 2.70 -> 2.78; F=256: 5.43 -> 5.46);
     // ctl.pair (option spmm_sweep_pair): -1 = that rule, 0 / 1 = forced (experiments)
     const bool pair = ctl.pair < 0 ? slabs >= 3 : ctl.pair != 0;
+#define SWEEP_LAUNCH_L(GRP, RR, LD)                                                                                    \
+    do {                                                                                                               \
+        if (unit) { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true, LD>), gr, bl, 0, s, a, B, row_scale, w);   \
+                    else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, false, LD>), gr, bl, 0, s, a, B, row_scale, w); }   \
+        else { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, true, LD>), gr, bl, 0, s, a, B, row_scale, w);       \
+               else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, false, LD>), gr, bl, 0, s, a, B, row_scale, w); }       \
+    } while (0)
 #define SWEEP_LAUNCH(GRP, RR)                                                                                          \
     do {                                                                                                               \
-        if (unit) { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true>), gr, bl, 0, s, a, B, row_scale, w);   \
-                    else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, false>), gr, bl, 0, s, a, B, row_scale, w); }   \
-        else { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, true>), gr, bl, 0, s, a, B, row_scale, w);       \
-               else hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, false, false>), gr, bl, 0, s, a, B, row_scale, w); }       \
+        if (GRP == 32 && ctl.loader) SWEEP_LAUNCH_L(32, RR, true); else SWEEP_LAUNCH_L(GRP, RR, false);                \
     } while (0)
 #define SWEEP_LAUNCH_R(GRP)                                                                                            \
     do {                                                                                                               \
@@ -1379,6 +1476,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     else SWEEP_LAUNCH_R(16);
 #undef SWEEP_LAUNCH_R
 #undef SWEEP_LAUNCH
+#undef SWEEP_LAUNCH_L
     return hipGetLastError();
 }
 

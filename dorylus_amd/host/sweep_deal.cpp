@@ -17,30 +17,52 @@
 
 namespace dory {
 
-// returns false on overflow; cap[g] = rows of group g, npos = T * R
-bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos) {
+// returns false on overflow; cap[g] = rows of group g, npos = T * R.
+// loader_relief: rows per sweep kept off lane groups 0 and 1 of every workgroup (the two groups of the workgroup's wave 0,
+// which also copies the next step's entries for the other fifteen waves -- csrc/spmm.hip, LOADER); the other groups take
+// them.  In the (shorter) last sweep the relief shrinks in proportion.
+bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos,
+                     uint32_t loader_relief) {
     if (R == 0) return false;
-    const uint32_t GS = std::max<uint32_t>(1, sweep_tiles) * 32u;      // groups per sweep and XCD
+    loader_relief = std::min(loader_relief, R / 2);                    // (a layout of few rows per group: little or nothing to take off)
+    const uint32_t tiles = std::max<uint32_t>(1, sweep_tiles);
+    const uint32_t GS = tiles * 32u;                                   // groups per sweep and XCD
     const uint32_t n_x = (nl + 7) / 8;
-    const uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);  // rows per group, summed over the sweeps
+    // rows of an ordinary group summed over the sweeps: the smallest `need` whose capacity (loader groups carry less) holds n_x
+    auto relief_of = [&](uint32_t rows) { return (uint32_t)(((uint64_t)loader_relief * rows + R / 2) / R); };   // of a sweep with `rows` per group
+    auto capacity = [&](uint32_t need) -> uint64_t {
+        const uint32_t S = (need + R - 1) / R, last = need - (S - 1) * R;
+        const uint64_t full = (uint64_t)GS * R - (uint64_t)2 * tiles * relief_of(R);
+        const uint64_t tail = (uint64_t)GS * last - (uint64_t)2 * tiles * std::min(relief_of(last), last);
+        return (uint64_t)(S - 1) * full + tail;
+    };
+    uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);
+    while (capacity(need) < n_x) ++need;
     const uint32_t S = (need + R - 1) / R;
     if ((uint64_t)8 * S * GS * R > 0xFFFFFFF0ull) return false;
     const uint32_t T = 8u * S * GS;
-    cap->assign(T, R);
     const uint32_t last = need - (S - 1) * R;
+    cap->assign(T, R);
     for (uint32_t x = 0; x < 8; ++x)
-        for (uint32_t g = 0; g < GS; ++g) (*cap)[(size_t)x * S * GS + (size_t)(S - 1) * GS + g] = last;
+        for (uint32_t sw = 0; sw < S; ++sw)
+            for (uint32_t g = 0; g < GS; ++g) {
+                const uint32_t rows = sw + 1 == S ? last : R;
+                const uint32_t rel = (g % 32u) < 2u ? std::min(relief_of(rows), rows) : 0u;
+                (*cap)[(size_t)x * S * GS + (size_t)sw * GS + g] = rows - rel;
+            }
     // make the capacity exact: the surplus comes off groups spread evenly over the last sweeps of all XCDs
-    uint64_t total = (uint64_t)8 * GS * need;
+    uint64_t total = (uint64_t)8 * capacity(need);
     const uint32_t L = 8u * GS;
     for (uint32_t sw = S; sw-- > 0 && total > nl;) {
         while (total > nl) {
             const uint64_t surplus = std::min<uint64_t>(total - nl, L);
             bool any = false;
             for (uint64_t k = 0; k < surplus; ++k) {
-                const uint32_t j = (uint32_t)(k * L / surplus);          // j-th group of sweep sw, counted over the XCDs
-                uint32_t &cg = (*cap)[(size_t)(j / GS) * S * GS + (size_t)sw * GS + j % GS];
-                if (cg) { --cg; --total; any = true; }
+                uint32_t j = (uint32_t)(k * L / surplus);                // j-th group of sweep sw, counted over the XCDs
+                for (uint32_t probe = 0; probe < L; ++probe, j = (j + 1) % L) {   // (a group without rows: the next one that has some)
+                    uint32_t &cg = (*cap)[(size_t)(j / GS) * S * GS + (size_t)sw * GS + j % GS];
+                    if (cg) { --cg; --total; any = true; break; }
+                }
             }
             if (!any) break;
         }
@@ -67,7 +89,7 @@ extern "C" int dory_sweep_deal(uint32_t items, uint32_t rows_per_group, uint32_t
                                uint32_t *group_rows_out, uint32_t *item_position) {
     std::vector<uint32_t> cap;
     uint32_t npos = 0;
-    if (!dory::sweep_deal_plan(items, rows_per_group, sweep_tiles, &cap, &npos)) return 1;
+    if (!dory::sweep_deal_plan(items, rows_per_group, sweep_tiles, &cap, &npos, 0)) return 1;
     if (positions_out) *positions_out = npos;
     if (group_rows_out) std::copy(cap.begin(), cap.end(), group_rows_out);
     if (item_position && !dory::sweep_deal_positions(items, rows_per_group, cap, item_position)) return 2;
