@@ -11,7 +11,7 @@ from dataclasses import dataclass, replace
 
 import numpy as np
 
-from ._lib import BACKWARD, FORWARD, GAT, GCN, Context, DoryError
+from ._lib import BACKWARD, FORWARD, GAT, GCN, Context, DoryError, load
 
 
 @dataclass
@@ -27,6 +27,12 @@ class Chunk:
     vertex: bool = True
 
 
+class _CChunk(C.Structure):
+    """struct dory_chunk (include/dorylus_host.h)"""
+    _fields_ = [("localId", C.c_uint32), ("globalId", C.c_uint32), ("lowBound", C.c_uint32), ("upBound", C.c_uint32),
+                ("layer", C.c_uint32), ("dir", C.c_int32), ("epoch", C.c_uint32), ("vertex", C.c_uint8)]
+
+
 class Engine:
     def __init__(self, ctx: Context, gnn: int, num_layers: int):
         self.ctx = ctx
@@ -34,34 +40,22 @@ class Engine:
         self.numLayers = num_layers
         self.epoch_hook = None
 
-    # ---- layer utils (engine/utils.cpp:707-753) ------------------------------------
+    # ---- layer utils (engine/utils.cpp:707-753): ONE implementation, host/engine.cpp's, reached through the C-ABI
+    # (dory_chunk_inc_layer needs neither an engine nor a device) -- this class keeps no copy of the state machine
+    def _inc_layer(self, gnn, c: Chunk) -> Chunk:
+        cin = _CChunk(c.localId, c.globalId, c.lowBound, c.upBound, c.layer, c.dir, c.epoch, 1 if c.vertex else 0)
+        cout = _CChunk()
+        lib = getattr(self.ctx, "lib", None) or load()      # (a recording stand-in for the context in tests has no library handle)
+        rc = lib.dory_chunk_inc_layer(gnn, self.numLayers, C.byref(cin), C.byref(cout))
+        if rc != 0:
+            raise DoryError(f"dory_chunk_inc_layer failed ({rc})")
+        return Chunk(cout.localId, cout.globalId, cout.lowBound, cout.upBound, cout.layer, cout.dir, cout.epoch, bool(cout.vertex))
+
     def incLayerGCN(self, c: Chunk) -> Chunk:
-        n = replace(c)
-        if n.dir == FORWARD:
-            n.layer += 1
-            if n.layer == self.numLayers:       # last forward layer merges into backward
-                n.dir = BACKWARD
-                n.layer -= 1
-        else:
-            if n.layer == 0:
-                n.dir = FORWARD
-                n.epoch += 1
-            else:
-                n.layer -= 1
-        return n
+        return self._inc_layer(GCN, c)
 
     def incLayerGAT(self, c: Chunk) -> Chunk:
-        n = replace(c)
-        if n.dir == FORWARD:
-            n.layer += 1
-        else:
-            if n.layer == 0:
-                n.dir = FORWARD
-                n.vertex = True
-                n.epoch += 1
-            else:
-                n.layer -= 1
-        return n
+        return self._inc_layer(GAT, c)
 
     def isLastLayer(self, c: Chunk) -> bool:
         return c.dir == BACKWARD and c.layer == 0 and c.vertex
