@@ -181,10 +181,22 @@ def main():
     V, E_full, DIMS = WORKLOADS[args.workload]
     E_target = int(E_full * args.scale)
     t_setup = time.time()
-    src, dst = synth_edges(args.graph, V, E_target)
     pw, pr = world, rank
     if args.emulate:
         pr, pw = (int(t) for t in args.emulate.split("/"))
+    if args.emulate and args.workload == "friendster" and args.graph == "uniform":
+        # one rank of config 5 alone: only the records incident to its block matter to it, and the whole 3.6 G-record
+        # list is 29 GB of host memory -- M undirected pairs {a, b}, a uniform in the block, b uniform in V, both
+        # directions, M such that the block's in-edge count is the real E / P (tests/test_gpu_fullscale.py does the same)
+        lo, hi = -(-pr * V // pw), -(-(pr + 1) * V // pw)
+        M = int(E_target / pw * pw / (pw + 1))
+        rng = np.random.default_rng(42 + pr)
+        a_ = rng.integers(lo, hi, M, dtype=np.uint32)
+        b_ = rng.integers(0, V, M, dtype=np.uint32)
+        src, dst = np.concatenate([a_, b_]), np.concatenate([b_, a_])
+        del a_, b_
+    else:
+        src, dst = synth_edges(args.graph, V, E_target)
     parts = (np.arange(V, dtype=np.int64) * pw // V).astype(np.int32)   # contiguous blocks
     if world > 1:   # every rank builds its own partition at the same time: share the host cores
         os.environ.setdefault("DORY_BUILD_THREADS", str(max(1, min(32, usable_cpus() // world))))
