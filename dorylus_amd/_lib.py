@@ -116,6 +116,7 @@ def load():
         "dory_engine_is_last_layer": [vp, vp],
         "dory_engine_report": [vp, cp, C.c_size_t],
         "dory_sweep_deal": [u32, u32, u32, vp, vp, vp],
+        "dory_sweep_deal_weighted": [u32, vp, u32, u32, u32, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

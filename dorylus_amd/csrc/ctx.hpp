@@ -231,7 +231,8 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r = 0 /* option spmm_sweep_rows: 0 = by fill */, int max_r = 10);
 // host/sweep_deal.cpp: rows per lane group of the K1s layout and the position of every (sorted) item
 bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<uint32_t> *cap, uint32_t *npos, uint32_t loader_relief = 0);
-bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos);
+bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos, uint32_t loader_lo = 0);
+bool sweep_deal_balanced(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, const uint64_t *w, uint32_t *pos);
 bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group);
 // per-context knobs and state of the K1s launches (nothing process-wide)
 struct SweepCtl {

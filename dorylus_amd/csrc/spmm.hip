@@ -23,6 +23,7 @@
 //     Infinity Cache.
 //   * optional row schedule (longest row first) for skewed degree distributions.
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "ctx.hpp"
@@ -1273,8 +1274,14 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
     std::vector<uint32_t> ipos(nl);
     if (layout & 2u) {
         std::vector<uint32_t> cap;
-        if (!sweep_deal_plan(nl, (uint32_t)R, sweep_tiles, &cap, &npos, loader_relief) || !sweep_deal_positions(nl, (uint32_t)R, cap, ipos.data()))
+        if (!sweep_deal_plan(nl, (uint32_t)R, sweep_tiles, &cap, &npos, loader_relief)) return hipErrorInvalidValue;
+        if (loader_relief) {   // groups of different capacities on purpose: deal by weight, edges in proportion to the rows
+            std::vector<uint64_t> wts(nl);
+            for (uint32_t i = 0; i < nl; ++i) wts[i] = items[i].w;
+            if (!sweep_deal_balanced(nl, (uint32_t)R, cap, wts.data(), ipos.data())) return hipErrorInvalidValue;
+        } else if (!sweep_deal_positions(nl, (uint32_t)R, cap, ipos.data())) {
             return hipErrorInvalidValue;
+        }
     } else {
         for (uint32_t i = 0; i < nl; ++i) ipos[i] = i;
     }

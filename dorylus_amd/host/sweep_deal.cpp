@@ -37,7 +37,12 @@ bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<
         return (uint64_t)(S - 1) * full + tail;
     };
     uint32_t need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);
-    while (capacity(need) < n_x) ++need;
+    const uint32_t S_plain = (need + R - 1) / R;                       // sweeps without any relief
+    for (;; --loader_relief) {                                         // never pay for the relief with one more sweep
+        need = std::max<uint32_t>(1, (n_x + GS - 1) / GS);
+        while (capacity(need) < n_x) ++need;
+        if ((need + R - 1) / R == S_plain || loader_relief == 0) break;
+    }
     const uint32_t S = (need + R - 1) / R;
     if ((uint64_t)8 * S * GS * R > 0xFFFFFFF0ull) return false;
     const uint32_t T = 8u * S * GS;
@@ -72,15 +77,57 @@ bool sweep_deal_plan(uint32_t nl, uint32_t R, uint32_t sweep_tiles, std::vector<
     return true;
 }
 
-// pos[i] = position of item i (items sorted by descending weight)
-bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos) {
+// pos[i] = position of item i (items sorted by descending weight).  Band b = the b-th heaviest row of every group that
+// takes part in it.  An ordinary group takes part in bands [0, cap); a loader group (lane groups 0 and 1 of a workgroup,
+// dealt fewer rows) sits out `loader_lo` of the HEAVIEST bands and the rest of its relief at the light end -- on a graph
+// with skewed degrees the light bands alone would take rows off it but hardly any edges (build_blocked_sweep chooses
+// loader_lo from the band weights).
+bool sweep_deal_positions(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, uint32_t *pos, uint32_t loader_lo) {
     const uint32_t T = (uint32_t)cap.size();
+    auto takes = [&](uint32_t g, uint32_t band) {
+        const uint32_t lo = (g % 32u) < 2u ? std::min(loader_lo, R - std::min(R, cap[g])) : 0u;
+        return band >= lo && band < lo + cap[g];
+    };
     uint32_t i = 0;
     for (uint32_t band = 0; band < R; ++band) {
-        if (!(band & 1u)) { for (uint32_t g = 0; g < T; ++g) if (cap[g] > band) { if (i >= nl) return false; pos[i++] = g * R + band; } }
-        else { for (uint32_t g = T; g-- > 0;) if (cap[g] > band) { if (i >= nl) return false; pos[i++] = g * R + band; } }
+        if (!(band & 1u)) { for (uint32_t g = 0; g < T; ++g) if (takes(g, band)) { if (i >= nl) return false; pos[i++] = g * R + band; } }
+        else { for (uint32_t g = T; g-- > 0;) if (takes(g, band)) { if (i >= nl) return false; pos[i++] = g * R + band; } }
     }
     return i == nl;
+}
+
+// The deal by weight: item i (sorted by descending weight w[i]) goes to the group with the smallest load per row slot
+// (load / cap) among those with a free slot -- longest-processing-time-first with row capacities.  Used when the groups'
+// capacities differ on purpose (loader groups): every group then carries edges in proportion to its rows whatever the
+// degree distribution, which skipping whole bands cannot do on a skewed graph.  Ties go to the lower group index: a pure
+// function of (weights, capacities).
+bool sweep_deal_balanced(uint32_t nl, uint32_t R, const std::vector<uint32_t> &cap, const uint64_t *w, uint32_t *pos) {
+    const uint32_t T = (uint32_t)cap.size();
+    struct Node { uint64_t load; uint32_t cap, g; };
+    auto worse = [](const Node &a, const Node &b) {     // a after b in the queue: a.load / a.cap > b.load / b.cap, then higher g
+        const unsigned __int128 l = (unsigned __int128)a.load * b.cap, r = (unsigned __int128)b.load * a.cap;
+        return l != r ? l > r : a.g > b.g;
+    };
+    std::vector<Node> heap;
+    heap.reserve(T);
+    for (uint32_t g = 0; g < T; ++g)
+        if (cap[g]) heap.push_back({0, cap[g], g});
+    std::make_heap(heap.begin(), heap.end(), worse);
+    std::vector<uint32_t> used(T, 0);
+    for (uint32_t i = 0; i < nl; ++i) {
+        if (heap.empty()) return false;
+        std::pop_heap(heap.begin(), heap.end(), worse);
+        Node n = heap.back();
+        heap.pop_back();
+        if (used[n.g] >= R) return false;
+        pos[i] = n.g * R + used[n.g]++;
+        n.load += w[i];
+        if (used[n.g] < cap[n.g]) {
+            heap.push_back(n);
+            std::push_heap(heap.begin(), heap.end(), worse);
+        }
+    }
+    return heap.empty();
 }
 
 }  // namespace dory
@@ -92,6 +139,19 @@ extern "C" int dory_sweep_deal(uint32_t items, uint32_t rows_per_group, uint32_t
     if (!dory::sweep_deal_plan(items, rows_per_group, sweep_tiles, &cap, &npos, 0)) return 1;
     if (positions_out) *positions_out = npos;
     if (group_rows_out) std::copy(cap.begin(), cap.end(), group_rows_out);
-    if (item_position && !dory::sweep_deal_positions(items, rows_per_group, cap, item_position)) return 2;
+    if (item_position && !dory::sweep_deal_positions(items, rows_per_group, cap, item_position, 0)) return 2;
+    return 0;
+}
+
+extern "C" int dory_sweep_deal_weighted(uint32_t items, const uint64_t *weights, uint32_t rows_per_group, uint32_t sweep_tiles,
+                                        uint32_t loader_relief, uint32_t *positions_out, uint32_t *group_rows_out,
+                                        uint32_t *item_position) {
+    if (!weights) return 1;
+    std::vector<uint32_t> cap;
+    uint32_t npos = 0;
+    if (!dory::sweep_deal_plan(items, rows_per_group, sweep_tiles, &cap, &npos, loader_relief)) return 1;
+    if (positions_out) *positions_out = npos;
+    if (group_rows_out) std::copy(cap.begin(), cap.end(), group_rows_out);
+    if (item_position && !dory::sweep_deal_balanced(items, rows_per_group, cap, weights, item_position)) return 2;
     return 0;
 }

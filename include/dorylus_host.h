@@ -119,6 +119,15 @@ int dory_engine_report(dory_engine *e, char *buf, size_t buflen);
  * (`items` entries, may be NULL): the position of item i.  0 = ok. */
 int dory_sweep_deal(uint32_t items, uint32_t rows_per_group, uint32_t sweep_tiles, uint32_t *positions_out,
                     uint32_t *group_rows_out, uint32_t *item_position);
+/* The layout of the 32-lane launches with a loader wave (csrc/spmm.hip, LOADER): lane groups 0 and 1 of every workgroup --
+ * the wave that also copies the next step's entries for the other fifteen -- get `loader_relief` rows fewer per sweep
+ * (proportionally fewer in a shorter last sweep; never so many that a sweep more would be needed: then less or none), and
+ * the items (sorted by descending weight = edge count, `weights` given) are dealt by weight, each to the group with the
+ * smallest load per row slot, so that every group carries edges in proportion to its rows whatever the degree
+ * distribution.  Outputs as dory_sweep_deal. */
+int dory_sweep_deal_weighted(uint32_t items, const uint64_t *weights, uint32_t rows_per_group, uint32_t sweep_tiles,
+                             uint32_t loader_relief, uint32_t *positions_out, uint32_t *group_rows_out,
+                             uint32_t *item_position);
 
 #ifdef __cplusplus
 }
