@@ -99,3 +99,43 @@ def test_sweep_knobs_are_per_context():
     assert np.array_equal(a.download(0, "ah"), ref)         # context a still runs its own layout
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("nb", [2, 3, 5, 12])
+def test_loader_wave_same_bits_as_without_it(nb):
+    """The loader wave only changes how entries and offsets reach LDS (and, through its relief, which position a row
+    takes): a row's sum is formed in the same order either way -- block order, edge order inside a block -- so K1s with and
+    without it must agree bit for bit, on a partition with ghost rows (two launches, the ghost one possibly a single
+    block), few and many blocks, F with a ragged last slab, and with the oracle to 1e-5."""
+    import dorylus_amd as da
+    import orc
+    from helpers import random_graph, rel_err
+    V, P, F = 30000, 2, 200
+    s, d = random_graph(77 + nb, V, 500000)
+    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+    part = da.Partition.build(s, d, parts, 1, P)
+    g = part.view()
+    N, Gs = int(g["localVtxCnt"]), int(g["srcGhostCnt"])
+    rng = np.random.default_rng(nb)
+    X = rng.uniform(-1, 1, (N, F)).astype(np.float32)
+    FG = rng.uniform(-1, 1, (Gs, F)).astype(np.float32)
+    ref = orc.aggregate_gcn(g["colPtr"], g["rowIdx"], g["cscVal"], g["norm"], X, FG)
+    outs = {}
+    for loader in (1, 0):
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, [F, 8, 4], V)
+        ctx.set_option("spmm_variant", 2)
+        ctx.set_option("spmm_blk_nb", nb)
+        ctx.set_option("spmm_sweep_loader", loader)
+        part.upload(ctx)
+        ctx.preallocate()
+        ctx.upload(0, "x", X)
+        ctx.upload(0, "fg", FG)
+        ctx.aggregate(0, da.FORWARD)
+        outs[loader] = ctx.download(0, "ah")
+        ctx.aggregate(0, da.FORWARD)
+        assert np.array_equal(ctx.download(0, "ah"), outs[loader])          # run to run
+        assert ctx.get_option("spmm_gate_timeouts") == 0
+        ctx.close()
+    assert rel_err(outs[1], ref) < 1e-5
+    assert np.array_equal(outs[1], outs[0])
