@@ -870,6 +870,9 @@ __device__ __forceinline__ void sweep_arrive(uint32_t sb, uint32_t t, uint32_t *
 // wave: taken by one wave (whose lane groups the layout deals fewer rows, SWEEP_LOADER_RELIEF) it is off the path of the
 // other fifteen, which issue nothing but gathers.
 
+#ifndef SWEEP_DMA_AUX
+#define SWEEP_DMA_AUX 2   // cache policy of the loader's copies: nt (the entry stream is read once: it must not push the window out of L2)
+#endif
 template <int GROUP, int R, bool UNIT, bool PAIR, bool LOADER>
 __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, BlockedAdj B, const float *row_scale,
                                                               SweepArgs w) {
@@ -979,11 +982,11 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
 #pragma unroll
         for (int j = 0; j < OFFB / 64; ++j)                  // the RW + 1 row offsets of the workgroup's positions
             if ((uint32_t)(j * 64 + lane) <= (uint32_t)RW)
-                __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)(j * 64 + lane), xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)(j * 64 + lane), xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, SWEEP_DMA_AUX);
 #pragma unroll
         for (int gg = 0; gg < NGRP; ++gg) {                  // one 1 KB run of entries per lane group, from the even entry at or before its first
             const uint64_t A0 = (base + (uint32_t)__builtin_amdgcn_readlane((int)gstart, gg)) & ~1ull;
-            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + lane), (lptr_t)&stage[buf * NGRP + gg][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + lane), (lptr_t)&stage[buf * NGRP + gg][0], 16, 0, SWEEP_DMA_AUX);
         }
     };
     auto uniform64 = [&](uint64_t v) -> uint64_t {
