@@ -155,6 +155,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra transform-first epochs (profiling runs: only the headline kernels)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="restrict the CPU baseline to the first rows (0 = the full epoch)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="rccl = the product path (grouped ncclSend/ncclRecv + ncclAllReduce over xGMI).  host = dry run of the "
+                         "N > 1 logic where RCCL cannot run: the packed rows and the gradients travel through "
+                         "dory_comm_set_host_transport over gloo (several ranks on ONE GPU: --device 0); diagnostic, not the metric")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,11 +174,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    dev = args.device if args.device >= 0 else local_rank
+    host_tx = args.transport == "host"
+    tdev = "cpu" if host_tx else "cuda"     # where the few scalars torch.distributed reduces live (gloo: host)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if host_tx:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
             dist.barrier()          # creates torch's communicator now, not inside the timed region
     import dorylus_amd as da
 
@@ -206,7 +217,7 @@ def main():
     N, Gs, Gd = int(g["localVtxCnt"]), int(g["srcGhostCnt"]), int(g["dstGhostCnt"])
     nnz_in, nnz_out = int(g["localInEdgeCnt"]), int(g["localOutEdgeCnt"])
 
-    ctx = da.Context(local_rank)
+    ctx = da.Context(dev)
     gat = args.gnn in ("gat", "gatmh")
     ctx.configure({"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[args.gnn], DIMS, V, rank, world)
     if args.gnn == "gatmh":
@@ -225,7 +236,9 @@ def main():
     ctx.labels_upload(labels[g["localToGlobal"]])
     ctx.weights_init_xavier()
     ctx.adam_config(0.01)
-    if world > 1:
+    if world > 1 and host_tx:
+        set_gloo_transport(ctx, dist, torch, rank, world)
+    elif world > 1:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.from_numpy(ctx.comm_unique_id()))
@@ -234,7 +247,7 @@ def main():
             ctx.comm_init(idt.cpu().numpy(), rank, world)
     halo_ok = None
     if world > 1 and not gat:
-        flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         halo_ok = bool(flag.item())
         if not halo_ok:
@@ -259,10 +272,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cnt = torch.tensor([nnz_in, nnz_out], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([nnz_in, nnz_out], dtype=torch.int64, device=tdev)
         dist.all_reduce(cnt)
         E_in, E_out = int(cnt[0]), int(cnt[1])
     else:
@@ -383,7 +396,7 @@ def main():
     if world > 1:
         ld1 = (DIMS[1] + 31) // 32 * 32
         mine = torch.tensor([nnz_in, N, Gs * ld1 * 4 + Gd * ld1 * 4, fam["halo"][0], fam["allreduce"][0],
-                             gates["timeouts"], gates["ungated_launches"]], dtype=torch.float64, device="cuda")
+                             gates["timeouts"], gates["ungated_launches"]], dtype=torch.float64, device=tdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         A = np.array([t.cpu().numpy() for t in allr])
@@ -422,6 +435,7 @@ def main():
                        "graph": args.graph, "vertices": V, "edges": E_in, "options": args.opt or None,
                        "layer0_order": "transform-first A(XW) [opt-in, not the reference order]" if tf_mode else "aggregate-first (AX)W",
                        "partitioning": f"contiguous x{world}" + (f" (emulating rank {args.emulate}, no exchange)" if args.emulate else ""),
+                       "transport": "RCCL over xGMI" if world > 1 and not host_tx else ("host callbacks over gloo (dry run of the N > 1 logic, not the metric)" if world > 1 else None),
                        "epoch_ms_min": float(np.min(epoch_ms)), "epoch_ms_median": float(np.median(epoch_ms))},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
@@ -508,6 +522,32 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what):
     eng.close()
     ctx.close()
     return res
+
+
+def set_gloo_transport(ctx, dist, torch, rank, world):
+    """--transport host: the bytes of the halo exchange and of the gradient sum through gloo (tests/test_gpu_multirank.py
+    does the same around dory_engine_run); everything else of the multi-rank path stays the library's."""
+    def alltoallv(send, sc, so, recv, rc, ro):
+        reqs, keep = [], []
+        for p in range(world):
+            if p == rank:
+                continue
+            if rc[p]:
+                t = torch.empty(int(rc[p]), dtype=torch.float32)
+                keep.append((t, int(ro[p]), int(rc[p])))
+                reqs.append(dist.irecv(t, p))
+            if sc[p]:
+                reqs.append(dist.isend(torch.from_numpy(send[int(so[p]):int(so[p] + sc[p])].copy()), p))
+        for r_ in reqs:
+            r_.wait()
+        for t, o, n in keep:
+            recv[o:o + n] = t.numpy()
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf.copy())
+        dist.all_reduce(t)
+        buf[:] = t.numpy()
+    ctx.set_host_transport(alltoallv, allreduce)
 
 
 class stdout_to_stderr:
