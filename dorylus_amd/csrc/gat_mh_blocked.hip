@@ -4,6 +4,17 @@
 
 namespace dory {
 
+// partial rows are written once and read once by the reduce kernels: non-temporal, so that they do not push the source
+// window the gathers live on out of the 4 MB L2
+typedef float gm_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4 *p, const float4 &v) {
+    __builtin_nontemporal_store((gm_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<gm_v4f *>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float4 *p) {
+    const gm_v4f t = __builtin_nontemporal_load(reinterpret_cast<const gm_v4f *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // ---- forward, source-blocked (K1b's idea applied to the attention-weighted sum) ---------------------------
 // The row-wise kernel above gathers Z rows from all over the graph: every gather misses L2.  Here the softmax
 // statistics come first (they only need el: N x K floats, L2-resident as a whole), then the weighted sum runs
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
             }
             e += n;
         }
-        if (row_ok && col_ok) p4[(size_t)v * nchunk + col] = acc;
+        if (row_ok && col_ok) nt_store4(p4 + (size_t)v * nchunk + col, acc);
     }
 }
 
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void gatmh_forward_reduce_kernel(GatMhArgs a, 
         const uint32_t k = min((col * 4) / a.D, a.K - 1);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t b = 0; b < nb; ++b) {
-            const float4 p = p4[(size_t)b * n + i];
+            const float4 p = nt_load4(p4 + (size_t)b * n + i);
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
         const size_t vk = (size_t)v * a.ldk + k;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
             }
             e += n;
         }
-        if (row_ok && col_ok && (li % HL) == 0) pst[((size_t)b * a.N + v) * a.K + k] = make_float4(t, a1, a2, 0.f);
+        if (row_ok && col_ok && (li % HL) == 0) nt_store4(pst + ((size_t)b * a.N + v) * a.K + k, make_float4(t, a1, a2, 0.f));
     }
 }
 
@@ -286,7 +297,7 @@ __global__ void gatmh_bwd_dst_reduce_kernel(GatMhArgs a, uint32_t nb, const floa
     const uint32_t v = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
     float t = 0.f, a1 = 0.f, a2 = 0.f;
     for (uint32_t b = 0; b < nb; ++b) {
-        const float4 p = pst[((size_t)b * a.N + v) * a.K + k];
+        const float4 p = nt_load4(pst + ((size_t)b * a.N + v) * a.K + k);
         t += p.x; a1 += p.y; a2 += p.z;
     }
     const float *zr = z + (size_t)v * a.ld + (size_t)k * a.D, *dr = d_o + (size_t)v * a.ld + (size_t)k * a.D;
@@ -378,8 +389,8 @@ __global__ __launch_bounds__(256) void gatmh_bwd_src_blocked_kernel(GatMhArgs a,
             e += n;
         }
         if (row_ok && col_ok) {
-            p4[(size_t)u * nchunk + col] = acc;
-            if ((li % HL) == 0) pdel[((size_t)b * a.N + u) * a.K + k] = del;
+            nt_store4(p4 + (size_t)u * nchunk + col, acc);
+            if ((li % HL) == 0) __builtin_nontemporal_store(del, pdel + ((size_t)b * a.N + u) * a.K + k);
         }
     }
 }
@@ -391,7 +402,7 @@ __global__ void gatmh_bwd_del_reduce_kernel(GatMhArgs a, uint32_t nb, const floa
     if (i >= (uint64_t)a.N * a.K) return;
     const uint32_t u = (uint32_t)(i / a.K), k = (uint32_t)(i % a.K);
     float del = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) del += pdel[((size_t)b * a.N + u) * a.K + k];
+    for (uint32_t b = 0; b < nb; ++b) del += __builtin_nontemporal_load(pdel + ((size_t)b * a.N + u) * a.K + k);
     const float *zr = z + (size_t)u * a.ld + (size_t)k * a.D, *dr = d_o + (size_t)u * a.ld + (size_t)k * a.D;
     float da = 0.f;
     for (uint32_t d = 0; d < a.D; ++d) da = fmaf(dr[d], zr[d], da);
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dz_reduce_kernel(GatMhArgs a, u
         const uint32_t k = min((col * 4) / a.D, a.K - 1);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t b = 0; b < nb; ++b) {
-            const float4 p = p4[(size_t)b * n + i];
+            const float4 p = nt_load4(p4 + (size_t)b * n + i);
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
         const float4 sv = st4[(size_t)u * lds4 + k];
