@@ -867,8 +867,8 @@ __device__ __forceinline__ void sweep_arrive(uint32_t sb, uint32_t t, uint32_t *
 // the NEXT step into LDS (LDS-DMA, three buffers) while all sixteen waves work on this one.  Why: a wave's vector loads
 // return in order, so a wave that requests its own entries -- they stream from HBM, 2-3 us -- cannot get its next gathers
 // back before them: 8-11 % of a launch with the gates on (profiles/r03_experiments.txt items 4, 9).  The wait is per
-// wave: taken by one wave (whose lane groups the layout deals fewer rows, SWEEP_LOADER_RELIEF) it is off the path of the
-// other fifteen, which issue nothing but gathers.
+// wave: taken by one wave (whose lane groups the layout deals fewer rows: option spmm_sweep_loader_relief,
+// host/sweep_deal.cpp) it is off the path of the other fifteen, which issue nothing but gathers.
 
 #ifndef SWEEP_DMA_AUX
 #define SWEEP_DMA_AUX 2   // cache policy of the loader's copies: nt (the entry stream is read once: it must not push the window out of L2)
