@@ -971,7 +971,9 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     // lane j < NGRP of wave 0: first offset of lane group j in step `stp` (the addresses of the entry copies come out of
     // a register: a load between two copies would have to wait for the first)
     auto group_starts = [&](uint32_t stp) -> uint32_t {
-        return stp < nbs ? (B.boff + (size_t)(w.b_lo + stp) * (B.npos + 1))[min(pos0 + (uint32_t)min(lane, NGRP - 1) * R, xend)] : 0u;
+        uint32_t ln = (uint32_t)min(lane, NGRP - 1);
+        asm volatile("" : "+v"(ln));                          // (opaque, as in copy_step)
+        return stp < nbs ? (B.boff + (size_t)(w.b_lo + stp) * (B.npos + 1))[min(pos0 + ln * R, xend)] : 0u;
     };
     auto block_base = [&](uint32_t stp) -> uint64_t { return stp < nbs ? B.bbase[w.b_lo + stp] : 0ull; };
     auto copy_step = [&](uint32_t stp, uint32_t gstart, uint64_t base) {
@@ -979,10 +981,12 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
         if constexpr (LOADER)
             if (lane == 0) { offl[buf][OFFB] = (uint32_t)base; offl[buf][OFFB + 1] = (uint32_t)(base >> 32); }
         const uint32_t *orow_b = B.boff + (size_t)bs * (B.npos + 1);
-#pragma unroll
+        uint32_t ln = (uint32_t)lane;                        // (opaque: the per-lane positions are two instructions each -- not
+        asm volatile("" : "+v"(ln));                         //  worth hoisted 64-bit registers that end up in scratch and are
+#pragma unroll                                               //  reloaded, one dependent miss after the other, by the loader)
         for (int j = 0; j < OFFB / 64; ++j)                  // the RW + 1 row offsets of the workgroup's positions
-            if ((uint32_t)(j * 64 + lane) <= (uint32_t)RW)
-                __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)(j * 64 + lane), xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, SWEEP_DMA_AUX);
+            if ((uint32_t)j * 64u + ln <= (uint32_t)RW)
+                __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)j * 64u + ln, xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, SWEEP_DMA_AUX);
 #pragma unroll
         for (int gg = 0; gg < NGRP; ++gg) {                  // one 1 KB run of entries per lane group, from the even entry at or before its first
             const uint64_t A0 = (base + (uint32_t)__builtin_amdgcn_readlane((int)gstart, gg)) & ~1ull;
@@ -1062,36 +1066,37 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
             for (int rr = 0; rr < R / 2; ++rr) {
                 const uint32_t o0 = ol[2 * rr], o1 = ol[2 * rr + 1], o2 = ol[2 * rr + 2];
                 const uint32_t lo = max(o0, cs), hi = min(o2, ce), mid = o1;
-                uint32_t e = lo;
-                for (; e + U <= hi; e += U) {
-                    uint2 en[U];
-                    float4 x[U];
+                if (lo < hi) {
+                    uint32_t e = lo;
+                    uint2 en[U];                                 // (read a batch ahead, as in the plain walk below)
 #pragma unroll
                     for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
+                    for (; e + U <= hi; e += U) {
+                        float4 x[U];
+                        float wv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = gather(en[u].x, true);
+                        for (int u = 0; u < U; ++u) { x[u] = gather(en[u].x, true); wv[u] = UNIT ? 1.f : __uint_as_float(en[u].y); }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float wv = UNIT ? 1.f : __uint_as_float(en[u].y);
-                        const bool first = e + u < mid;
-                        acc[2 * rr] = fma4(first ? wv : 0.f, x[u], acc[2 * rr]);
-                        acc[2 * rr + 1] = fma4(first ? 0.f : wv, x[u], acc[2 * rr + 1]);
+                        for (int u = 0; u < U; ++u) en[u] = st[e + U + u - cs];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool first = e + u < mid;
+                            acc[2 * rr] = fma4(first ? wv[u] : 0.f, x[u], acc[2 * rr]);
+                            acc[2 * rr + 1] = fma4(first ? 0.f : wv[u], x[u], acc[2 * rr + 1]);
+                        }
                     }
-                }
-                if (e < hi) {
-                    const uint32_t n = hi - e;
-                    uint2 en[U - 1];
-                    float4 x[U - 1];
+                    if (e < hi) {
+                        const uint32_t n = hi - e;
+                        float4 x[U - 1];
 #pragma unroll
-                    for (int u = 0; u < U - 1; ++u) en[u] = st[min(e + u, hi - 1) - cs];
+                        for (int u = 0; u < U - 1; ++u) x[u] = gather(en[u].x, (uint32_t)u < n);
 #pragma unroll
-                    for (int u = 0; u < U - 1; ++u) x[u] = gather(en[u].x, (uint32_t)u < n);
-#pragma unroll
-                    for (int u = 0; u < U - 1; ++u) {
-                        const float wv = (uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f;
-                        const bool first = e + u < mid;
-                        acc[2 * rr] = fma4(first ? wv : 0.f, x[u], acc[2 * rr]);
-                        acc[2 * rr + 1] = fma4(first ? 0.f : wv, x[u], acc[2 * rr + 1]);
+                        for (int u = 0; u < U - 1; ++u) {
+                            const float wv = (uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f;
+                            const bool first = e + u < mid;
+                            acc[2 * rr] = fma4(first ? wv : 0.f, x[u], acc[2 * rr]);
+                            acc[2 * rr + 1] = fma4(first ? 0.f : wv, x[u], acc[2 * rr + 1]);
+                        }
                     }
                 }
             }
@@ -1100,29 +1105,34 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
             for (int r = 0; r < R; ++r) {
                 const uint32_t rlo = ol[r], rhi = ol[r + 1];
                 const uint32_t lo = max(rlo, cs), hi = min(rhi, ce);
-                uint32_t e = lo;
-                for (; e + U <= hi; e += U) {               // full batches: nothing predicated
+                if (lo < hi) {
+                    // the entries of a batch are read while the batch before it is in flight (the LDS round trip is off
+                    // the chain LDS -> gathers -> sums that a wave repeats ~30 times per step); slots past the row's end
+                    // read whatever is staged behind it (inside the LDS allocation) and are switched off below
+                    uint32_t e = lo;
                     uint2 en[U];
-                    float4 x[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
+                    for (; e + U <= hi; e += U) {               // full batches: nothing predicated
+                        float4 x[U];
+                        float wv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = gather(en[u].x, true);
+                        for (int u = 0; u < U; ++u) { x[u] = gather(en[u].x, true); wv[u] = UNIT ? 1.f : __uint_as_float(en[u].y); }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) acc[r] = fma4(UNIT ? 1.f : __uint_as_float(en[u].y), x[u], acc[r]);
-                }
-                if (e < hi) {                                // tail: 1 .. U-1 edges
-                    const uint32_t n = hi - e;
-                    uint2 en[U - 1];
-                    float4 x[U - 1];
+                        for (int u = 0; u < U; ++u) en[u] = st[e + U + u - cs];
 #pragma unroll
-                    for (int u = 0; u < U - 1; ++u) en[u] = st[min(e + u, hi - 1) - cs];
+                        for (int u = 0; u < U; ++u) acc[r] = fma4(wv[u], x[u], acc[r]);
+                    }
+                    if (e < hi) {                                // tail: 1 .. U-1 edges
+                        const uint32_t n = hi - e;
+                        float4 x[U - 1];
 #pragma unroll
-                    for (int u = 0; u < U - 1; ++u)
-                        x[u] = gather(en[u].x, (uint32_t)u < n);
+                        for (int u = 0; u < U - 1; ++u)
+                            x[u] = gather(en[u].x, (uint32_t)u < n);
 #pragma unroll
-                    for (int u = 0; u < U - 1; ++u)
-                        acc[r] = fma4((uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f, x[u], acc[r]);
+                        for (int u = 0; u < U - 1; ++u)
+                            acc[r] = fma4((uint32_t)u < n ? (UNIT ? 1.f : __uint_as_float(en[u].y)) : 0.f, x[u], acc[r]);
+                    }
                 }
             }
             }
