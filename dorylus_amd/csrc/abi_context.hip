@@ -164,7 +164,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_sweep_loader_relief"] = 3;  // ... and the layout gives each of its two lane groups this many rows fewer per sweep (set before the layout is built)
     c->opt["spmm_sweep_reserve_cus"] = 4;    // K1s under an exchange in flight: CUs per XCD its sweeps leave to the RCCL kernels
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
-    c->opt["spmm_sweep_window_kb"] = 2432;   // K1s: source window per block (two must fit one XCD's 4 MB L2)
+    c->opt["spmm_sweep_window_kb"] = 0;      // K1s: source window per block; 0 = 2432 KB (two live windows in one XCD's 4 MB L2), 3584 KB for partitions of <= 4 rows per lane group
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;

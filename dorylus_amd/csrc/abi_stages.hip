@@ -55,7 +55,13 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     if (built || na) return DORY_OK;
     if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: the sweep layout would have to be built while recording");
     const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
-    const uint64_t window = (uint64_t)c->opt["spmm_sweep_window_kb"] << 10;
+    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);   // the deal is made for the 32-lane launches
+    // source window per block.  0 = by the rows a lane group holds: a step costs ~3 us whatever it gathers, and a small
+    // partition (one rank of 8: four rows per group) gathers little per step -- fewer, larger windows win there although
+    // two of them no longer fit the L2 (measured, one rank of 8 of the Reddit-size graph: 2432 / 3072 / 3584 / 4096 / 5120 KB
+    // = 3.34 / 3.22 / 3.16 / 3.21 / 3.38 ms per epoch; ranks of 4, 2 and the whole graph: 2432 KB stays best)
+    const uint64_t window_kb = c->opt["spmm_sweep_window_kb"] ? (uint64_t)c->opt["spmm_sweep_window_kb"] : (R <= 4 ? 3584u : 2432u);
+    const uint64_t window = window_kb << 10;
     const uint64_t nb_est = ((uint64_t)NG * group * 16u + window - 1) / window + 1;
     // the whole source slab in one L2 (Cora-sized graphs): K1 gathers from L2 anyway.  Thousands of windows (Amazon-,
     // Friendster-sized partitions on a random graph: a row has a fraction of an edge per window): the per-(block,
@@ -65,7 +71,6 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
         na = true;
         return DORY_OK;
     }
-    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);   // the deal is made for the 32-lane launches
     HIPCK(c, build_blocked_sweep(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal, c->N,
                                  NG, csc ? c->nnz_in : c->nnz_out, want_nb, (uint32_t)group * 16u, window, R, &S, c->compute,
                                  (uint32_t)c->opt["spmm_sweep_layout"], std::min<uint32_t>(32u, c->cus_per_xcd),
