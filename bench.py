@@ -180,6 +180,11 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's exchange kernels run beside the local-source K1s launch, one workgroup (= one CU K1s cannot use) per channel;
+        # K1s leaves spmm_sweep_reserve_cus = 4 CUs per XCD (32 in all) to them.  Bound the channels so that the reserve holds
+        # whatever the library's default for this topology is (16 channels: 2 CUs per XCD; the halo of a Reddit-size rank is
+        # ~100 MB per exchange).  Unmeasured on hardware: setdefault, so a run can override it; reported in multi_gpu.rccl_env.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         with stdout_to_stderr():
             if host_tx:
                 dist.init_process_group(backend="gloo")
@@ -411,6 +416,7 @@ def main():
                  "allreduce_ms_per_epoch_max_rank": float((A[:, 4] / args.steps).max()),
                  "spmm_gate_timeouts_per_rank": [int(v) for v in A[:, 5]], "spmm_ungated_launches_per_rank": [int(v) for v in A[:, 6]],
                  "halo_overlap": int(ctx.get_option("halo_overlap")), "spmm_sweep_reserve_cus": gates["spmm_sweep_reserve_cus"],
+                 "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS")},
                  "note": "halo = one all-to-all-v of h (forward) and one of grad (backward) per epoch, " + str(DIMS[1]) + " floats per ghost row; "
                          "ms are HIP-event times on the comm stream (pack + grouped ncclSend/ncclRecv + unpack), overlapped with the interior-source SpMM blocks"}
 

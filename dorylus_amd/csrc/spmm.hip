@@ -795,10 +795,13 @@ struct SweepArgs {
     uint32_t nsweeps;    // slabs * ceil(tiles_x / G)
     uint32_t b_lo, b_hi; // source blocks of this launch
     uint32_t *done;      // [8][nsweeps][b_hi - b_lo][32] arrival words + 1 "gates off" flag
-    uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots); 8: no gates (diagnostic)
+    uint32_t flags;      // 2: second launch of an aggregation (pieces of split rows add to their slots); 8: no gates (diagnostic);
+                         // 32: launched beside an exchange in flight (CUs left to its kernels): a back-off class of its own
     float *split_partial;// [B.nslots][ld]: bare sums of the pieces of split rows
     uint32_t *stat;      // per context, never reset by a launch: [0] gate timeouts, [1] first launch number that gates again,
-                         // [2] launches that ran (partly) ungated after a timeout, [3] spare
+                         // [2] launches that ran (partly) ungated after a timeout, [3] as [1] for the launches beside an exchange
+                         // (a timeout there -- RCCL holding more CUs than reserved -- must not switch off the gates of
+                         // the launches that run alone, and the other way round)
     uint32_t seq;        // launch number of the context
 };
 
@@ -835,7 +838,7 @@ __device__ __forceinline__ void sweep_gate(const SweepArgs &w, bool gated, uint3
                         // and the context's next SWEEP_BACKOFF launches run ungated -- same results, counted
                         if (__hip_atomic_exchange(gates_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                             __hip_atomic_fetch_add(w.stat + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_fetch_max(w.stat + 1, w.seq + 1u + SWEEP_BACKOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_max(w.stat + ((w.flags & 32u) ? 3 : 1), w.seq + 1u + SWEEP_BACKOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         break;
                     }
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(SWEEP_NT) void spmm_sweep_kernel(SpmmArgs a, Blocke
     uint32_t *dq = w.done + ((size_t)xcd * w.nsweeps + q) * nbs * 32;
     uint32_t *gates_off = w.done + (size_t)8 * w.nsweeps * nbs * 32;
     // gates of this launch: off by request (diagnostic), or while the context backs off after a timeout
-    const bool gated = !(w.flags & 8u) && !(w.seq < __hip_atomic_load(w.stat + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const bool gated = !(w.flags & 8u) && !(w.seq < __hip_atomic_load(w.stat + ((w.flags & 32u) ? 3 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (!gated && blockIdx.x == 0 && threadIdx.x == 0 && !(w.flags & 8u))
         __hip_atomic_fetch_add(w.stat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1463,7 +1466,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     w.nsweeps = slabs * spp;
     w.b_lo = b_lo; w.b_hi = b_hi;
     w.done = done;
-    w.flags = flags;
+    w.flags = flags | (reserve ? 32u : 0u);
     w.split_partial = split_partial;
     w.stat = ctl.stat;
     w.seq = ctl.seq;

@@ -74,6 +74,36 @@ def test_gate_timeouts_counted_and_results_unchanged_under_cu_mask():
     ctx.close()
 
 
+@pytest.mark.timeout(300)
+def test_gate_backoff_of_launches_beside_an_exchange_is_a_class_of_its_own():
+    """A timeout of a launch that runs beside an exchange (flag 32: CUs left to RCCL kernels, which may hold more than
+    reserved) must not switch off the gates of the launches that run alone -- the ghost-block launch right behind it waits
+    for the exchange and has the chip to itself -- and the other way round."""
+    import dorylus_amd as da
+    V, E, F = 60000, 1500000, 128
+    g = _graph(V, E, 5)
+    ctx = _ctx(da, g, V, F)
+    ctx.aggregate(0, da.FORWARD)
+    ref = ctx.download(0, "ah")
+    ctx.set_option("spmm_sweep_flags", 32)                  # what launch_spmm_sweep sets when an exchange is in flight
+    ctx.debug_occupy_cus(96, 150000)
+    time.sleep(0.01)
+    ctx.aggregate(0, da.FORWARD)
+    timeouts = ctx.get_option("spmm_gate_timeouts")
+    assert timeouts >= 1
+    ctx.sync()                                              # the occupier is gone
+    ctx.set_option("spmm_sweep_flags", 0)
+    ungated = ctx.get_option("spmm_ungated_launches")
+    for _ in range(4):                                      # launches that run alone: gated, although inside the other class's back-off
+        ctx.aggregate(0, da.FORWARD)
+    assert ctx.get_option("spmm_ungated_launches") == ungated and ctx.get_option("spmm_gate_timeouts") == timeouts
+    ctx.set_option("spmm_sweep_flags", 32)
+    ctx.aggregate(0, da.FORWARD)                            # the class that timed out is still backing off
+    assert ctx.get_option("spmm_ungated_launches") == ungated + 1
+    assert np.array_equal(ctx.download(0, "ah"), ref)
+    ctx.close()
+
+
 def test_sweep_knobs_are_per_context():
     """spmm_sweep_rows / spmm_sweep_pair were process-wide in round 2: a second context must not inherit them."""
     import dorylus_amd as da
