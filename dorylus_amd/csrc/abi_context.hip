@@ -167,7 +167,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_sweep_window_kb"] = 0;      // K1s: source window per block; 0 = 2432 KB (two live windows in one XCD's 4 MB L2), 3584 KB for partitions of <= 4 rows per lane group
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
     c->opt["spmm_slab"] = 0;
-    c->opt["spmm_order"] = 1;
+    c->opt["spmm_order"] = 1;    // K1: rows longest first -- 1 = when the degrees are skewed (max > 8 x mean), 2 = always, 0 = never
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
@@ -330,6 +330,16 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     if ((rc = upload_array(c, &c->csrVal, csr_values, nnz_out))) return rc;
     if ((rc = upload_array(c, &c->norm, vtx_norms, (uint64_t)N))) return rc;
     auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
+    {   // is the degree distribution skewed enough for the longest-first row schedule to pay?  (Amazon-size uniform graph:
+        // 129 ms per epoch in row order against 134 longest first; R-MAT of the same size: 118 against 104)
+        auto skew = [&](const uint64_t *ptr, uint64_t nnz) {
+            uint64_t mx = 0;
+            for (uint32_t v = 0; v < N; ++v) mx = std::max<uint64_t>(mx, ptr[v + 1] - ptr[v]);
+            return N > 0 && mx * (uint64_t)N > 8ull * nnz + 8ull * N;
+        };
+        c->skewIn = skew(column_ptrs, nnz_in);
+        c->skewOut = skew(row_ptrs, nnz_out);
+    }
     if ((rc = upload_array(c, &c->orderIn, oi.data(), (uint64_t)N))) return rc;
     if ((rc = upload_array(c, &c->orderOut, oo.data(), (uint64_t)N))) return rc;
     for (int d = 0; d < 2; ++d) {   // K1's interior / boundary row split (partitions with ghosts), each direction on its own

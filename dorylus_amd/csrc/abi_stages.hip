@@ -104,7 +104,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
     a.self_mode = self_mode;
     a.xl = xl.d; a.xg = (xg && xg->rows) ? xg->d : nullptr; a.out = out.d;   // nullptr: no ghost rows (the blocked kernel then skips the select)
     a.accumulate = accumulate;
-    a.order = c->opt["spmm_order"] ? (csc ? c->orderIn : c->orderOut) : nullptr;
+    a.order = (c->opt["spmm_order"] >= 2 || (c->opt["spmm_order"] == 1 && (csc ? c->skewIn : c->skewOut))) ? (csc ? c->orderIn : c->orderOut) : nullptr;
     const bool static_vals = val == (csc ? c->cscVal : c->csrVal) && !(c->gnn == DORY_GAT && csc);  // GAT rewrites cscVal
     if (c->opt["spmm_variant"] == 2 && (static_vals || row_scale) && c->N > 0 && a.ld >= 32) {
         // K1s: register accumulators, every workgroup sweeps all source blocks of its own even layout (spmm.hip).

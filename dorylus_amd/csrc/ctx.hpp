@@ -116,6 +116,7 @@ struct dory_ctx {
     float *cscVal = nullptr, *csrVal = nullptr, *norm = nullptr;
     // longest-row-first schedules for the SpMM (built at upload)
     uint32_t *orderIn = nullptr, *orderOut = nullptr;
+    bool skewIn = false, skewOut = false;   // max degree > 8 x mean: K1 walks the rows longest first (option spmm_order = 1)
     // K1 under a halo exchange in flight: rows whose sources are all local ("interior", first nInt entries) run
     // first, the rows that read ghost rows after the exchange; both parts longest row first
     uint32_t *splitIn = nullptr, *splitOut = nullptr;   // N entries: interior rows, then boundary rows

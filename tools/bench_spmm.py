@@ -74,7 +74,7 @@ def main():
         _, _, ld, _ = ctx.info(0, "x")
         comp = E * 8 + 8 * (N + 1) + 4 * N + 4 * F * N + 4 * F * N
         for variant in a.variants:
-          for order in ((1, 0) if variant == 0 else (1,)):
+          for order in ((2, 0) if variant == 0 else (1,)):
            for grp, nbq in ([(16, 0)] if variant == 0 else [(g_ + 100 * f_, n_) for f_ in a.forms for g_ in a.groups for n_ in a.nbs]):
             for slab in (a.slabs if variant == 0 else [0]):
                 if slab and slab >= ld:
