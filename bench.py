@@ -84,6 +84,34 @@ def synth_edges(kind, V, E, seed=42):
     return np.concatenate([s, d]), np.concatenate([d, s])
 
 
+def block_bounds(V, pw, r):
+    """contiguous vertex blocks: vertex v belongs to rank v * pw // V"""
+    return -(-r * V // pw), -(-(r + 1) * V // pw)
+
+
+def synth_incident_edges(V, E, pr, pw, seed=42):
+    """The records of a uniform synthetic graph of ~E directed edges that are incident to rank pr's contiguous block --
+    all a rank needs (a record matters to a rank iff its source or its destination is local; the reference's DataLoader
+    skips the others, dataloader.cpp:268-297), without the whole record list in host memory (Friendster: 29 GB).  The
+    undirected pairs between block i and block j come from a generator seeded by the UNORDERED pair {i, j}, so the ranks of
+    a real N-GPU run generate the same pair set for the edges they share: the partitions are those of ONE global graph.
+    Expected pairs: E/2 x 2/pw^2 between two different blocks, E/2 / pw^2 inside a block."""
+    lo, hi = block_bounds(V, pw, pr)
+    half = E // 2
+    srcs, dsts = [], []
+    for j in range(pw):
+        i0, j0 = min(pr, j), max(pr, j)
+        m = half // (pw * pw) if j == pr else 2 * half // (pw * pw)
+        rng = np.random.default_rng([seed, i0, j0])
+        lo_i, hi_i = block_bounds(V, pw, i0)
+        lo_j, hi_j = block_bounds(V, pw, j0)
+        a_ = rng.integers(lo_i, hi_i, m, dtype=np.uint32)      # endpoint in block i0
+        b_ = rng.integers(lo_j, hi_j, m, dtype=np.uint32)      # endpoint in block j0
+        srcs += [a_, b_]
+        dsts += [b_, a_]
+    return np.concatenate(srcs), np.concatenate(dsts)
+
+
 def splitmix_uniform(seed, rows_global, cols, lo=-1.0, hi=1.0):
     """host twin of the device counter RNG (csrc/elementwise.hip fill_uniform_kernel)"""
     rows_global = np.asarray(rows_global, dtype=np.uint64)
@@ -160,6 +188,8 @@ def main():
                          "N > 1 logic where RCCL cannot run: the packed rows and the gradients travel through "
                          "dory_comm_set_host_transport over gloo (several ranks on ONE GPU: --device 0); diagnostic, not the metric")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
+    ap.add_argument("--with-friendster", action="store_true",
+                    help="also time BASELINE config 5 as rank 0 of 8 holds it (key friendster_rank0of8: ~2 min of setup, 58 GB of ghost rows)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,11 +210,8 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL's exchange kernels run beside the local-source K1s launch, one workgroup (= one CU K1s cannot use) per channel;
-        # K1s leaves spmm_sweep_reserve_cus = 4 CUs per XCD (32 in all) to them.  Bound the channels so that the reserve holds
-        # whatever the library's default for this topology is (16 channels: 2 CUs per XCD; the halo of a Reddit-size rank is
-        # ~100 MB per exchange).  Unmeasured on hardware: setdefault, so a run can override it; reported in multi_gpu.rccl_env.
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+        # (RCCL's exchange kernels run beside the local-source K1s launch and take CUs from it; no channel cap is set here --
+        #  the warm-up samples spmm_sweep_reserve_cus instead, below -- and whatever NCCL_* the caller exported is reported)
         with stdout_to_stderr():
             if host_tx:
                 dist.init_process_group(backend="gloo")
@@ -193,6 +220,10 @@ def main():
             dist.barrier()          # creates torch's communicator now, not inside the timed region
     import dorylus_amd as da
 
+    preflight = None
+    if world > 1:
+        preflight = first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev)
+
     global DIMS
     V, E_full, DIMS = WORKLOADS[args.workload]
     E_target = int(E_full * args.scale)
@@ -200,17 +231,10 @@ def main():
     pw, pr = world, rank
     if args.emulate:
         pr, pw = (int(t) for t in args.emulate.split("/"))
-    if args.emulate and args.workload == "friendster" and args.graph == "uniform":
-        # one rank of config 5 alone: only the records incident to its block matter to it, and the whole 3.6 G-record
-        # list is 29 GB of host memory -- M undirected pairs {a, b}, a uniform in the block, b uniform in V, both
-        # directions, M such that the block's in-edge count is the real E / P (tests/test_gpu_fullscale.py does the same)
-        lo, hi = -(-pr * V // pw), -(-(pr + 1) * V // pw)
-        M = int(E_target / pw * pw / (pw + 1))
-        rng = np.random.default_rng(42 + pr)
-        a_ = rng.integers(lo, hi, M, dtype=np.uint32)
-        b_ = rng.integers(0, V, M, dtype=np.uint32)
-        src, dst = np.concatenate([a_, b_]), np.concatenate([b_, a_])
-        del a_, b_
+    if args.workload in ("friendster", "amazon") and args.graph == "uniform" and pw > 1:
+        # configs 4 and 5 as a rank holds them (one rank emulated, or a real N-GPU run): only the records incident to
+        # the rank's block, generated consistently across ranks (tests/test_gpu_fullscale.py does the same)
+        src, dst = synth_incident_edges(V, E_target, pr, pw)
     else:
         src, dst = synth_edges(args.graph, V, E_target)
     parts = (np.arange(V, dtype=np.int64) * pw // V).astype(np.int32)   # contiguous blocks
@@ -266,6 +290,27 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # ---- N > 1: how many CUs do the exchange's kernels really take beside K1s?  Three extra warm-up epochs, one per
+    # candidate reserve, smallest first; a reserve holds if no rank counted a gate timeout in its epoch ----
+    reserve_probe = None
+    if world > 1 and not gat and ctx.get_option("spmm_variant") == 2 and not any(o.startswith("spmm_sweep_reserve_cus=") for o in args.opt):
+        reserve_probe = {"tried": [], "chosen": None}
+        for cand in (2, 4, 8):
+            ctx.set_option("spmm_sweep_reserve_cus", cand)
+            ctx.set_option("spmm_gates_rearm", 1)            # a timeout of the previous candidate must not hide this one's
+            before = ctx.get_option("spmm_gate_timeouts")
+            eng.run(1)
+            d_ = torch.tensor([ctx.get_option("spmm_gate_timeouts") - before], dtype=torch.int64, device=tdev)
+            dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+            reserve_probe["tried"].append({"reserve_cus": cand, "gate_timeouts_max_rank": int(d_.item())})
+            if int(d_.item()) == 0:
+                reserve_probe["chosen"] = cand
+                break
+        if reserve_probe["chosen"] is None:                 # even 8 CUs per XCD were not enough: keep 8, the counters below say so
+            reserve_probe["chosen"] = 8
+        ctx.set_option("spmm_sweep_reserve_cus", reserve_probe["chosen"])
+        ctx.set_option("spmm_gates_rearm", 1)
+
     # ---- warmup, then exactly K timed steps ------------------------------------------
     if args.warmup:
         eng.run(args.warmup)
@@ -297,7 +342,7 @@ def main():
 
     # ---- roofline of the dominant kernel (K1 SpMM): HIP events recorded during the timed steps ----
     fam = {}
-    for f in ("spmm", "gemm", "loss", "halo", "allreduce", "adam"):
+    for f in ("spmm", "gemm", "loss", "halo", "allreduce", "adam", "halo_deferred", "halo_hidden", "spmm_beside_halo"):
         ms, n = ctx.timing_get(f)
         fam[f] = (ms, n)
     ctx.timing_enable(False)
@@ -340,7 +385,11 @@ def main():
     # memory path delivers 64 B per clock: 64 B x 256 CUs x 2.3 GHz = 37.7 TB/s (the HBM fraction above stays the headline)
     roofline["l1_path"] = {"peak_TBps": 37.7, "achieved_TBps": roofline["l2_gather_TBps"],
                            "frac": round(roofline["l2_gather_TBps"] / 37.7, 4),
-                           "what": "gathered row bytes (E x ld x 4 per launch) / launch time against 64 B/clk/CU x 256 CUs x 2.3 GHz"}
+                           "frac_of_guide_l2_34.5_TBps": round(roofline["l2_gather_TBps"] / 34.5, 4),
+                           "frac_of_measured_gather_ceiling_31_TBps": round(roofline["l2_gather_TBps"] / 31.0, 4),
+                           "what": "gathered row bytes (E x ld x 4 per launch) / launch time against (a) 64 B/clk/CU x 256 CUs x 2.3 GHz, "
+                                   "(b) MI355X_MICROARCH.md's aggregate L2 figure, (c) what a pure L2-resident gather reaches on this "
+                                   "chip (tools/probes/gather_probe.hip, profiles/r02_gather_probe_l2_ceiling.txt: 30-32 TB/s)"}
 
     # second kernel family: the dense transforms on fp32 MFMA (all GEMMs of the epoch, split-K stages included)
     gemm_ms, gemm_n = fam["gemm"]
@@ -401,7 +450,8 @@ def main():
     if world > 1:
         ld1 = (DIMS[1] + 31) // 32 * 32
         mine = torch.tensor([nnz_in, N, Gs * ld1 * 4 + Gd * ld1 * 4, fam["halo"][0], fam["allreduce"][0],
-                             gates["timeouts"], gates["ungated_launches"]], dtype=torch.float64, device=tdev)
+                             gates["timeouts"], gates["ungated_launches"], fam["halo_deferred"][0], fam["halo_hidden"][0],
+                             fam["spmm_beside_halo"][0]], dtype=torch.float64, device=tdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         A = np.array([t.cpu().numpy() for t in allr])
@@ -416,6 +466,13 @@ def main():
                  "allreduce_ms_per_epoch_max_rank": float((A[:, 4] / args.steps).max()),
                  "spmm_gate_timeouts_per_rank": [int(v) for v in A[:, 5]], "spmm_ungated_launches_per_rank": [int(v) for v in A[:, 6]],
                  "halo_overlap": int(ctx.get_option("halo_overlap")), "spmm_sweep_reserve_cus": gates["spmm_sweep_reserve_cus"],
+                 # exchange time hidden under the local-source launch / exchange time, per rank (HIP events of both streams on
+                 # the device clock; exchanges the compute stream waited for at once are not in the denominator)
+                 "halo_overlap_fraction_per_rank": [round(float(h / d), 4) if d > 0 else None for h, d in zip(A[:, 8], A[:, 7])],
+                 "halo_overlap_fraction_min": (float(np.min([h / d for h, d in zip(A[:, 8], A[:, 7]) if d > 0])) if (A[:, 7] > 0).any() else None),
+                 "halo_deferred_ms_per_epoch_max_rank": float((A[:, 7] / args.steps).max()),
+                 "spmm_beside_halo_ms_per_epoch_max_rank": float((A[:, 9] / args.steps).max()),
+                 "reserve_probe": reserve_probe, "preflight": preflight,
                  "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS")},
                  "note": "halo = one all-to-all-v of h (forward) and one of grad (backward) per epoch, " + str(DIMS[1]) + " floats per ghost row; "
                          "ms are HIP-event times on the comm stream (pack + grouped ncclSend/ncclRecv + unpack), overlapped with the interior-source SpMM blocks"}
@@ -470,25 +527,136 @@ def main():
         del src, dst
         out["rmat"] = extra_epoch(da, part_r, part_r.view(), "gcn", V, steps_x, warm_x,
                                   "same GCN epoch on an R-MAT graph (a=.57 b=.19 c=.19, SURVEY 8d): same V and E, max degree ~8e5")
+        del part_r
+        out["amazon_rank0of8"] = rank_of_8_epoch(da, "amazon", max(5, steps_x), warm_x)
+        if args.with_friendster:
+            out["friendster_rank0of8"] = rank_of_8_epoch(da, "friendster", max(5, steps_x), warm_x)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def extra_epoch(da, part, g, gnn, V, steps, warmup, what):
+def rank_of_8_epoch(da, workload, steps, warmup):
+    """BASELINE configs 4 / 5 as ONE rank of the 8-GPU run holds them (rank 0 of a contiguous 8-way split of the uniform
+    synthetic graph of the real size; compute only -- no peers, so no exchange: the layer-0 ghost rows are resident like
+    fg@0 from file, deeper ghost tensors are whatever they were).  Same epoch loop and timing as the headline."""
+    Vw, Ew, dims = WORKLOADS[workload]
+    t0 = time.time()
+    src, dst = synth_incident_edges(Vw, Ew, 0, 8)
+    parts = (np.arange(Vw, dtype=np.int64) * 8 // Vw).astype(np.int32)
+    part = da.Partition.build(src, dst, parts, 0, 8)
+    del src, dst, parts
+    what = {"amazon": "BASELINE config 4 (Amazon GCN 3-layer 300-64-64-25, 9.43 M vertices, 231.6 M edges) as rank 0 of 8 holds it",
+            "friendster": "BASELINE config 5 (Friendster GCN 2-layer 256-48-51, 65.6 M vertices, 3.61 G edges) as rank 0 of 8 holds it"}[workload]
+    res = extra_epoch(da, part, part.view(), "gcn", Vw, steps, warmup,
+                      what + ": uniform synthetic graph, only the records incident to the rank's block generated, compute only", dims=dims, ghosts=True)
+    res["setup_s"] = round(time.time() - t0, 1)
+    part.close()
+    return res
+
+
+def first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev):
+    """N > 1, before any partition is built: the two collectives of the path on a 64-vertex-per-rank toy partition, through
+    the same C-ABI calls the epoch uses -- a grouped ncclSend/ncclRecv exchange of 1 MB per peer (dory_halo_exchange, both
+    directions) and a 311 KB ncclAllReduce (dory_weight_update) -- under a 60 s watchdog that names the call it was in.
+    A first run on real xGMI then fails here, in seconds and with the failing call's name, not minutes later inside a
+    timed region.  Results are checked (ghost rows bit-equal to the owners', gradient sum exact).  Over --transport host the
+    same calls run with the bytes through gloo."""
+    import threading
+    stage = {"name": "start", "t0": time.time()}
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(60.0):
+            sys.stderr.write("bench.py preflight: rank %d STUCK for 60 s in: %s\n" % (rank, stage["name"]))
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def enter(name):
+        stage["name"] = name
+        stage["t0"] = time.time()
+    n, dims = 64, [19, 4096, 4]                     # 64 rows x 4096 floats = 1 MB per peer; dW0 = 19 x 4096 floats = 311 KB
+    V = n * world
+    v = np.arange(V, dtype=np.uint32)
+    nxt = ((v + n) % V).astype(np.uint32)           # vertex i of block r <-> vertex i of block r + 1: a ring of blocks
+    src, dst = np.concatenate([v, nxt]), np.concatenate([nxt, v])
+    parts = (v // n).astype(np.int32)
+    t0 = time.time()
+    enter("dory_partition_build (toy ring partition)")
+    part = da.Partition.build(src, dst, parts, rank, world)
+    g = part.view()
+    ctx = da.Context(dev)
+    ctx.configure(da.GCN, dims, V, rank, world)
+    part.upload(ctx, parts)
+    ctx.preallocate()
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    if host_tx:
+        set_gloo_transport(ctx, dist, torch, rank, world)
+    else:
+        enter("ncclGetUniqueId + broadcast of the id (torch.distributed)")
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.from_numpy(ctx.comm_unique_id()))
+        with stdout_to_stderr():
+            dist.broadcast(idt, 0)
+            enter("dory_comm_init (ncclCommInitRank, %d ranks)" % world)
+            ctx.comm_init(idt.cpu().numpy(), rank, world)
+    res = {"vertices_per_rank": n, "bytes_per_peer": n * dims[1] * 4, "allreduce_bytes": dims[0] * dims[1] * 4}
+    enter("dory_halo_exchange(layer 1, FORWARD): grouped ncclSend/ncclRecv, 1 MB per peer")
+    ctx.fill_uniform(0, "h", 7, -1.0, 1.0, g["localToGlobal"])
+    t1 = time.time()
+    ctx.halo_exchange(1, da.FORWARD)
+    ctx.sync()
+    res["halo_forward_s"] = round(time.time() - t1, 4)
+    ok = np.array_equal(ctx.download(1, "fg"), splitmix_uniform(7, g["srcGhost"], dims[1]))
+    enter("dory_halo_exchange(layer 1, BACKWARD): grouped ncclSend/ncclRecv, 1 MB per peer")
+    ctx.fill_uniform(1, "grad", 9, -1.0, 1.0, g["localToGlobal"])
+    t1 = time.time()
+    ctx.halo_exchange(1, da.BACKWARD)
+    ctx.sync()
+    res["halo_backward_s"] = round(time.time() - t1, 4)
+    ok = ok and np.array_equal(ctx.download(0, "bg"), splitmix_uniform(9, g["dstGhost"], dims[1]))
+    enter("dory_weight_update(layer 0): ncclAllReduce(sum) of 311 KB + Adam")
+    ctx.weight_grad_set(0, np.full((dims[0], dims[1]), float(rank + 1), np.float32))
+    t1 = time.time()
+    ctx.weight_update(0)
+    ctx.sync()
+    res["allreduce_adam_s"] = round(time.time() - t1, 4)
+    ok = ok and bool(np.all(ctx.weight_grad_get(0) == np.float32(world * (world + 1) / 2)))
+    enter("closing the toy context (ncclCommDestroy)")
+    ctx.close()
+    part.close()
+    enter("torch.distributed all_reduce of the verdict")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    done.set()
+    res["ok"] = bool(flag.item())
+    res["seconds"] = round(time.time() - t0, 2)
+    res["transport"] = "host callbacks over gloo" if host_tx else "RCCL"
+    if not res["ok"]:
+        raise SystemExit("bench.py preflight FAILED on rank %d: exchanged ghost rows or the gradient sum are wrong (%r)" % (rank, res))
+    return res
+
+
+def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=False):
     """one more configuration on one GPU: fresh context, same epoch loop, K timed steps after W warm-up steps"""
     import torch
+    DIMS_ = dims or DIMS
     N = int(g["localVtxCnt"])
     ctx = da.Context(0)
     gat = gnn in ("gat", "gatmh")
-    ctx.configure({"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[gnn], DIMS, V, 0, 1)
+    ctx.configure({"gcn": da.GCN, "gat": da.GAT, "gatmh": da.GATMH}[gnn], DIMS_, V, 0, 1)
     if gnn == "gatmh":
         ctx.gatmh_heads([8, 1])
     part.upload(ctx, None)
     ctx.preallocate()
     ctx.fill_uniform(0, "h" if gat else "x", 1, -1.0, 1.0, g["localToGlobal"])
-    labels = np.random.default_rng(2).integers(0, DIMS[-1], V).astype(np.uint32)
+    if ghosts and int(g["srcGhostCnt"]) and not gat:          # one rank of a P-way split alone: layer-0 ghost rows "from file"
+        ctx.fill_uniform(0, "fg", 1, -1.0, 1.0, g["srcGhost"])
+    labels = np.random.default_rng(2).integers(0, DIMS_[-1], V).astype(np.uint32)
     ctx.labels_upload(labels[g["localToGlobal"]])
     ctx.weights_init_xavier()
     ctx.adam_config(0.01)
@@ -505,15 +673,34 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what):
     ms = (time.perf_counter() - t0) * 1e3 / steps
     fam = {f: ctx.timing_get(f) for f in ("spmm", "gemm", "loss", "adam")}
     nnz_in, nnz_out = int(g["localInEdgeCnt"]), int(g["localOutEdgeCnt"])
-    edges = (4 * nnz_in + 2 * nnz_out) if gat else (2 * nnz_in + nnz_out)
+    nl_ = len(DIMS_) - 1
+    edges = (4 * nnz_in + 2 * nnz_out) if gat else (nl_ * nnz_in + (nl_ - 1) * nnz_out)
     res = {"what": what, "ms_per_step": ms, "steps": steps, "warmup": warmup, "edges_per_s": edges / (ms * 1e-3),
            "spmm_variant": ctx.get_option("spmm_variant"),
            "kernel_ms_per_epoch": {k: round(v[0] / steps, 4) for k, v in fam.items() if v[1]}}
+    if gnn == "gcn" and dims is not None and fam["spmm"][1]:
+        # roofline of this partition's aggregations (K1 row gather on partitions of this size: HBM / fabric bound):
+        # compulsory bytes of the epoch's 2L-1 launches over their HIP-event time, and the gathered row bytes
+        # against the ~6.3 TB/s a streaming kernel achieves on this HBM (MI355X_MICROARCH.md)
+        Gs_, Gd_ = int(g["srcGhostCnt"]), int(g["dstGhostCnt"])
+        algo = sum(spmm_algorithmic_bytes(N, Gs_, nnz_in, DIMS_[l]) for l in range(nl_)) + \
+            sum(spmm_algorithmic_bytes(N, Gd_, nnz_out, DIMS_[l]) for l in range(1, nl_))
+        gathered = 4 * (sum(nnz_in * ((DIMS_[l] + 31) // 32 * 32) for l in range(nl_)) +
+                        sum(nnz_out * ((DIMS_[l] + 31) // 32 * 32) for l in range(1, nl_)))
+        t = fam["spmm"][0] / steps * 1e-3
+        res["partition"] = {"local_vertices": N, "src_ghosts": Gs_, "dst_ghosts": Gd_, "in_edges": nnz_in, "out_edges": nnz_out}
+        res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": None,
+                           "kernel": "spmm_rows_kernel<GROUP,CHUNKS> (K1 row gather; %d launches per epoch)" % (2 * nl_ - 1),
+                           "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
+                           "gathered_bytes_per_epoch": int(gathered), "gathered_TBps": round(gathered / t / 1e12, 3),
+                           "gathered_frac_of_achievable_hbm_6.3_TBps": round(gathered / t / 1e12 / 6.3, 4),
+                           "traffic_note": "HBM-side bytes of this configuration: profiles/r04_k1_amazon_rank_pmc_fetch_size.txt"}
     if gnn == "gatmh" and fam["spmm"][1]:
         # compulsory bytes of the epoch's six edge passes (forward, destination-side and source-side backward sweeps of both
         # layers: 4 over the CSC, 2 over the CSR), each: the index stream once + pointers + one read and one write of an
         # N x ld row tensor (z / dO in, o / dz out; the per-(vertex, head) scores and statistics are K floats per row)
-        lds = [(DIMS[1] + 31) // 32 * 32, (DIMS[2] + 31) // 32 * 32]
+        lds = [(DIMS_[1] + 31) // 32 * 32, (DIMS_[2] + 31) // 32 * 32]
         algo = 0
         for ld_, K_ in ((lds[0], 8), (lds[1], 1)):
             for nnz in (nnz_in, nnz_in, nnz_out):

@@ -181,6 +181,7 @@ int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) 
     HIPCK(c, hipStreamWaitEvent(c->comm, c->ev_a, 0));
     {
         Timed t(c, "halo", c->comm);
+        Timed td(c, (defer && c->opt["halo_overlap"]) ? "halo_deferred" : "halo_waited", c->comm);   // (overlap bookkeeping: abi_internal.hpp)
         HIPCK(c, launch_gather_rows(c->send_buf, src->d, src->ld, w, p.d_send_lvids, p.send_total, c->comm));
         if (c->tx_a2a) {   // host transport: same pack / unpack / events, the bytes travel through the caller
             c->tx_send.resize((size_t)p.send_total * w);
@@ -232,6 +233,8 @@ int dory_halo_exchange(dory_ctx *c, uint32_t layer, int dir) {
     Tensor *src, *ghost;
     int rc = halo_tensors(c, layer, dir, &src, &ghost);
     if (rc) return rc;
+    // a forward exchange of layer 0 rewrites fg@0 (a peer may have uploaded a new x): a cached ah@0 no longer holds
+    if (layer == 0 && dir == DORY_FORWARD) c->ah0_valid = false;
     // consumers on the compute stream wait for the ghosts at once, or (halo_overlap) when the first of them needs
     // the ghost rows -- see wait_halo()
     return exchange_rows(c, dir, src, ghost, true);

@@ -18,6 +18,7 @@ int fail(dory_ctx *c, int code, const char *fmt, ...) {
 }
 
 void drain_timing(dory_ctx *c) {
+    const dory_ctx::Pending *halo = nullptr;   // the last deferred exchange seen: the next "spmm_beside_halo" ran beside it
     for (auto &p : c->pending) {
         (void)hipEventSynchronize(p.b);
         float ms = 0.f;
@@ -25,8 +26,20 @@ void drain_timing(dory_ctx *c) {
             c->times[p.fam].total_ms += ms;
             c->times[p.fam].launches += 1;
         }
-        c->ev_pool.push_back({p.a, p.b});
+        if (p.fam == "halo_deferred") halo = &p;
+        if (p.fam == "spmm_beside_halo" && halo) {
+            // both intervals on the clock of the exchange's first event: [0, he] and [ss, se]
+            float he = 0.f, ss = 0.f, se = 0.f;
+            if (hipEventElapsedTime(&he, halo->a, halo->b) == hipSuccess && hipEventElapsedTime(&ss, halo->a, p.a) == hipSuccess &&
+                hipEventElapsedTime(&se, halo->a, p.b) == hipSuccess) {
+                const float hidden = std::max(0.f, std::min(he, se) - std::max(0.f, ss));
+                c->times["halo_hidden"].total_ms += hidden;
+                c->times["halo_hidden"].launches += 1;
+            }
+            halo = nullptr;
+        }
     }
+    for (auto &p : c->pending) c->ev_pool.push_back({p.a, p.b});
     c->pending.clear();
 }
 
@@ -149,12 +162,12 @@ int dory_create(int device, dory_ctx **out) {
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->d_stat, 2 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&c->sweep_stat, 4 * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&c->sweep_stat, SWEEP_STAT_WORDS * sizeof(uint32_t)) != hipSuccess) {
         delete c;
         return fail(nullptr, DORY_ERR_HIP, "stream/event creation failed");
     }
     (void)hipMemset(c->d_stat, 0, 2 * sizeof(float));
-    (void)hipMemset(c->sweep_stat, 0, 4 * sizeof(uint32_t));
+    (void)hipMemset(c->sweep_stat, 0, SWEEP_STAT_WORDS * sizeof(uint32_t));
     c->own_compute = c->own_comm = true;
     c->opt["spmm_variant"] = 2;      // 2: K1s register-accumulating sweep over the blocked adjacency, 1: K1b (partial rows), 0: K1 only
     c->opt["spmm_sweep_flags"] = 0;          // K1s: reserved for experiments (bit 1 is the library's own "second launch" mark)
@@ -789,6 +802,14 @@ int dory_debug_occupy_cus(dory_ctx *c, uint32_t workgroups, uint64_t usec) {
 
 int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
     CHECK_CTX(c);
+    if (key && !strcmp(key, "spmm_gates_rearm")) {   // write-only: end a K1s gate back-off now (both launch classes); the counters stay.
+        // For a caller that has just changed what caused the timeouts (bench.py trying another spmm_sweep_reserve_cus).
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        const uint32_t zero = 0;
+        HIPCK(c, hipMemcpy(c->sweep_stat + 1, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        HIPCK(c, hipMemcpy(c->sweep_stat + 3, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        return DORY_OK;
+    }
     if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");
     c->opt[key] = value;
     c->ah0_valid = false;   // (another kernel variant sums in another order: a cached ah@0 is only kept across identical settings)

@@ -67,6 +67,10 @@ struct Timed {
         c->pending.push_back({fam, a, b});
     }
 };
+// Overlap bookkeeping (timing on only): the exchange whose ghosts are still landing when the compute stream goes on is
+// recorded as family "halo_deferred", the launch that runs beside it (local-source blocks / interior rows) as
+// "spmm_beside_halo"; drain_timing intersects the two intervals on the device's clock into "halo_hidden".
+// bench.py: multi_gpu.halo_overlap_fraction = halo_hidden / halo_deferred.
 
 void drain_timing(dory_ctx *c);
 int alloc_tensor(dory_ctx *c, Tensor &t, uint64_t rows, uint32_t cols);

@@ -141,17 +141,17 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             if (two) {
                 // under an exchange in flight the RCCL kernels need CUs of their own
                 const uint32_t reserve = c->halo_pending ? (uint32_t)c->opt["spmm_sweep_reserve_cus"] : 0u;
-                ctl.seq = c->sweep_seq++;
-                HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, ctl, sflags, c->scratch, reserve));
+                {
+                    Timed tb(c, c->halo_pending ? "spmm_beside_halo" : "spmm_local_first", c->compute);
+                    HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb_local, done, c->compute, ctl, sflags, c->scratch, reserve));
+                }
                 if ((rc = wait_halo(c))) return rc;
                 SpmmArgs a2 = a;
                 a2.self_mode = 0;
                 a2.accumulate = 1;
-                ctl.seq = c->sweep_seq++;
                 HIPCK(c, launch_spmm_sweep(a2, S, group, row_scale, G, S.nb_local, S.nb, done, c->compute, ctl, sflags | 2u, c->scratch));
             } else {
                 if ((rc = wait_halo(c))) return rc;
-                ctl.seq = c->sweep_seq++;
                 HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, S.nb, done, c->compute, ctl, sflags, c->scratch));
             }
             HIPCK(c, launch_spmm_sweep_combine(a, S, row_scale, c->scratch, c->compute));
@@ -180,7 +180,10 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             const uint32_t nb_local = std::min(B.nb, c->N / B.SB);
             const bool split = (c->halo_pending || c->opt["spmm_blk_force_split"]) && nb_local > 0 && nb_local < B.nb;
             if (split) {
-                HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, nb_local, c->compute));
+                {
+                    Timed tb(c, c->halo_pending ? "spmm_beside_halo" : "spmm_local_first", c->compute);
+                    HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, 0, nb_local, c->compute));
+                }
                 if ((rc = wait_halo(c))) return rc;
                 HIPCK(c, launch_spmm_blocked_part(a, B, c->partial, group, row_scale != nullptr, nb_local, B.nb, c->compute));
             } else {
@@ -213,7 +216,10 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         SpmmArgs part = a;
         part.order = split;
         part.rows = nInt;
-        HIPCK(c, launch_spmm(part, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+        {
+            Timed tb(c, c->halo_pending ? "spmm_beside_halo" : "spmm_local_first", c->compute);
+            HIPCK(c, launch_spmm(part, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+        }
         int rc = wait_halo(c);
         if (rc) return rc;
         part.order = split + nInt;

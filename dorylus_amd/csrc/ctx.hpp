@@ -130,8 +130,10 @@ struct dory_ctx {
     bool blkIn_built = false, blkOut_built = false;
     bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
     uint32_t cus_per_xcd = 32;                  // K1s: workgroups per sweep
-    uint32_t *sweep_stat = nullptr;             // K1s: 4 device words (gate timeouts, backoff horizon, ungated launches, spare)
-    uint32_t sweep_seq = 0;                     // K1s: launches so far
+    uint32_t *sweep_stat = nullptr;             // K1s: SWEEP_STAT_WORDS device words that outlive the launches: gate timeouts, back-off horizon of
+                                                // the launches that run alone, ungated launches, back-off horizon of the launches
+                                                // beside an exchange, launch number (bumped on the device: hipGraph replays advance
+                                                // it), workgroups of the launch in flight that have left
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
     float *partial = nullptr;
@@ -240,10 +242,9 @@ struct SweepCtl {
     int force_r = 0;            // option spmm_sweep_rows
     int pair = -1;              // option spmm_sweep_pair
     bool loader = true;         // option spmm_sweep_loader: wave 0 of a workgroup copies the next step's entries for all (32-lane launches)
-    uint32_t *stat = nullptr;   // 4 device words that outlive the launches: gate timeouts, launch number that gates again,
-                                // ungated launches, spare
-    uint32_t seq = 0;           // launch number
+    uint32_t *stat = nullptr;   // SWEEP_STAT_WORDS device words that outlive the launches (dory_ctx::sweep_stat)
 };
+constexpr int SWEEP_STAT_WORDS = 8;
 size_t sweep_scratch_bytes(const BlockedAdj &B, uint32_t ld, int group, uint32_t G, uint32_t nblocks, int force_r = 0);
 hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, const float *row_scale, uint32_t cus_per_xcd,
                              uint32_t b_lo, uint32_t b_hi, uint32_t *done /* sweep_scratch_bytes() */, hipStream_t s,

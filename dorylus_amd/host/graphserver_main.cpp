@@ -185,36 +185,46 @@ int main(int argc, char **argv) {
     CK(dory_weights_init_xavier(ctx));
     CK(dory_adam_config(ctx, lr));
     if (numNodes > 1) {  // RCCL bootstrap over a file in tmpdir (single node, shared filesystem)
-        // one id file per job: the launcher's rendezvous port (or DORY_JOB_ID) is the nonce that keeps concurrent jobs
-        // apart.  A file left behind by a crashed earlier job with the same nonce (MASTER_PORT is usually a constant)
-        // is older than this process: the other ranks only accept a file written after they started.
-        const char *nonce = getenv("DORY_JOB_ID");
-        if (!nonce || !*nonce) nonce = getenv("MASTER_PORT");
-        const std::string idFile = tmpDir + "/dorylus_rccl_id." + (nonce && *nonce ? nonce : "default") + ".bin";
+        // One id file per job.  The file carries the job's nonce behind the 128-byte id and a rank accepts it by CONTENT:
+        //  * DORY_JOB_ID set (run/run-dorylus-hip: launcher pid + start time -- unique per job): the nonce must match; when
+        //    a rank starts relative to rank 0 does not matter (staggered per-machine launches), nor does any clock;
+        //  * no job id: the rendezvous port is the nonce, which a crashed earlier job may have used too -- then the file must
+        //    also be no older than the job's start (DORY_JOB_START, epoch seconds, from the launcher) or, lacking that,
+        //    than ten minutes before this rank started (ranks of one job do not start further apart than that).
+        const char *job = getenv("DORY_JOB_ID");
+        const bool unique_job = job && *job;
+        const char *nonce = unique_job ? job : getenv("MASTER_PORT");
+        if (!nonce || !*nonce) nonce = "default";
+        char nonce_buf[64];
+        memset(nonce_buf, 0, sizeof(nonce_buf));
+        strncpy(nonce_buf, nonce, sizeof(nonce_buf) - 1);
+        const std::string idFile = tmpDir + "/dorylus_rccl_id." + nonce_buf + ".bin";
         unsigned char id[128];
         if (nodeId == 0) {
             if (dory_comm_unique_id(id)) DIE("ncclGetUniqueId failed");
             remove(idFile.c_str());   // stale file of an earlier job with the same nonce
             const std::string tmp = idFile + ".tmp";
             FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, 128, f) != 128) DIE("cannot write %s", tmp.c_str());
+            if (!f || fwrite(id, 1, 128, f) != 128 || fwrite(nonce_buf, 1, sizeof(nonce_buf), f) != sizeof(nonce_buf)) DIE("cannot write %s", tmp.c_str());
             fclose(f);
             rename(tmp.c_str(), idFile.c_str());
         } else {
+            time_t not_before = proc_start.tv_sec - 600;
+            if (const char *js = getenv("DORY_JOB_START")) { if (*js) not_before = (time_t)strtoll(js, nullptr, 10); }
             bool ok = false;
             for (int tries = 0; tries < 600 && !ok; ++tries) {
                 struct stat sb;
-                if (stat(idFile.c_str(), &sb) == 0 &&
-                    (sb.st_mtim.tv_sec > proc_start.tv_sec ||
-                     (sb.st_mtim.tv_sec == proc_start.tv_sec && sb.st_mtim.tv_nsec >= proc_start.tv_nsec))) {
+                if (stat(idFile.c_str(), &sb) == 0 && (unique_job || sb.st_mtim.tv_sec >= not_before)) {
                     if (FILE *f = fopen(idFile.c_str(), "rb")) {
-                        ok = fread(id, 1, 128, f) == 128;
+                        char got[64];
+                        ok = fread(id, 1, 128, f) == 128 && fread(got, 1, sizeof(got), f) == sizeof(got) &&
+                             memcmp(got, nonce_buf, sizeof(got)) == 0;
                         fclose(f);
                     }
                 }
                 if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }
-            if (!ok) DIE("timed out waiting for %s", idFile.c_str());
+            if (!ok) DIE("timed out waiting for %s (job nonce '%s')", idFile.c_str(), nonce_buf);
         }
         CK(dory_comm_init(ctx, id, (int)nodeId, (int)numNodes));
         if (nodeId == 0) { std::this_thread::sleep_for(std::chrono::seconds(2)); unlink(idFile.c_str()); }

@@ -206,7 +206,10 @@ int dory_ctx_describe(dory_ctx *ctx, int *gnn_type, uint32_t *num_layers, uint32
                       uint32_t *num_nodes, uint32_t *local_vtx_cnt);
 /* average device time (ms) and launch count of a kernel family since the last
  * reset, measured with HIP events on the stream the kernel runs on; names:
- * "spmm", "gemm", "loss", "edge", "halo", "adam". */
+ * "spmm", "gemm", "loss", "edge", "halo", "allreduce", "adam".  Overlap of an exchange with the aggregation that runs beside
+ * it ("halo_overlap"): "halo_deferred" = exchanges the compute stream did not wait for at once, "spmm_beside_halo" = the
+ * launches that ran beside them (local-source blocks / interior rows), "halo_hidden" = the part of each such exchange that
+ * lies inside its launch's interval on the device clock (total_ms; hidden / deferred = the overlap fraction). */
 int dory_timing_enable(dory_ctx *ctx, int on);
 int dory_timing_get(dory_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
 int dory_timing_reset(dory_ctx *ctx);
@@ -214,7 +217,8 @@ int dory_timing_reset(dory_ctx *ctx);
  * "spmm_gate_timeouts" (K1s sweeps whose workgroups were not co-resident within the polling bound: the launch and the
  * context's next 16 K1s launches ran without gates -- same results, unsynchronised gather rate) and
  * "spmm_ungated_launches"; "epoch_graph_recorded".  dory_timing_get("spmm_gate_timeouts") returns the same pair
- * (launches = timeouts, total_ms = ungated launches). */
+ * (launches = timeouts, total_ms = ungated launches).  Write-only key "spmm_gates_rearm": ends a gate back-off at once
+ * (a caller that has just changed its cause, e.g. another "spmm_sweep_reserve_cus"); the counters stay. */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
 /* Diagnostic (no reference counterpart): hold `workgroups` whole CUs for `usec` microseconds with a sleeping kernel on
@@ -248,8 +252,9 @@ int dory_transform_first_layer(dory_ctx *ctx, uint32_t layer);
  * recomputes A_hat x every epoch, gcn_ops.cpp:139-148, and so does the default here).  In full-graph training "ah"@0 is a
  * constant of the run: "x" and "fg"@0 come from files and the adjacency never changes.  With the option on,
  * dory_aggregate(0, DORY_FORWARD) returns at once while "ah"@0 still holds the aggregate of the current inputs: it is
- * recomputed after any dory_tensor_upload / dory_tensor_fill_uniform / dory_halo_unpack* of a layer-0 tensor,
- * dory_graph_upload, dory_preallocate or dory_set_option.  (A caller that writes "x" through the device pointer of
+ * recomputed after any dory_tensor_upload / dory_tensor_fill_uniform / dory_halo_unpack* of a layer-0 tensor, a
+ * dory_halo_exchange(0, DORY_FORWARD) (it rewrites "fg"@0: a peer may hold a new "x"), dory_graph_upload,
+ * dory_preallocate or dory_set_option.  (A caller that writes "x" through the device pointer of
  * dory_tensor_info must invalidate by one of those calls itself.)  Results are bit-identical to the uncached run: the
  * same kernel produced the kept tensor.  Not combined with a recorded epoch (the recording always contains the
  * aggregation).  dory_get_option "gcn_cache_ah0_skips" counts the aggregations answered from the kept tensor. */

@@ -1,4 +1,6 @@
-"""Halo-exchange plan from a partition's graph.<id>.bin fields + the .parts vector.
+"""Test-side restatement of the halo-exchange plan (the product computes it in host/partition.cpp: dory_partition_upload /
+Partition.recv_plan); two GPU tests build their multi-context plans with it.  From a partition's graph.<id>.bin fields +
+the .parts vector.
 
 Send side: the per-peer lists the reference stores (forwardGhostsList /
 backwardGhostsList, graph/dataloader.cpp:277-297).  Receive side: the reference

@@ -44,3 +44,15 @@ def test_bench_multirank_dry_run_on_one_gpu(world):
     assert m["spmm_gate_timeouts_per_rank"] is not None and len(m["spmm_ungated_launches_per_rank"]) == world
     assert "host callbacks" in d["config"]["transport"]
     assert d["roofline"] is not None and d["roofline"]["traffic"] is None      # (the PMC traffic figure is the 1-GPU run's)
+    # round 4, first-contact hardening: (a) the preflight ran its three collectives and verified them, (b) the warm-up
+    # sampled the CUs left to the exchange's kernels, (c) the overlap of the exchanges with the local-source launches is
+    # reported per rank
+    pf = m["preflight"]
+    assert pf["ok"] is True and pf["bytes_per_peer"] == 64 * 4096 * 4 and pf["allreduce_bytes"] == 19 * 4096 * 4
+    assert pf["halo_forward_s"] >= 0 and pf["allreduce_adam_s"] >= 0 and "gloo" in pf["transport"]
+    rp = m["reserve_probe"]
+    assert rp["chosen"] in (2, 4, 8) and rp["tried"][0]["reserve_cus"] == 2
+    assert m["spmm_sweep_reserve_cus"] == rp["chosen"]
+    fr = m["halo_overlap_fraction_per_rank"]
+    assert len(fr) == world and all(f is None or 0.0 <= f <= 1.0 for f in fr)
+    assert m["halo_deferred_ms_per_epoch_max_rank"] >= 0 and m["spmm_beside_halo_ms_per_epoch_max_rank"] >= 0

@@ -98,7 +98,7 @@ def test_gat_mh_partitioned_epoch_vs_oracle(P):
     import dorylus_amd as da
     import gat_mh_oracle as go
     import partition_oracle as po
-    from dorylus_amd.halo import halo_plan
+    from halo_plan_ref import halo_plan
     from helpers import rel_err
     dims, heads, V, E = [24, 64, 6], [4, 1], 240, 2600
     rng = np.random.default_rng(17)

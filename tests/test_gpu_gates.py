@@ -47,21 +47,23 @@ def test_gate_timeouts_counted_and_results_unchanged_under_cu_mask():
     # the same while a sleeping kernel holds 96 of the 256 CUs (12 per XCD) for the whole sequence
     ctx = _ctx(da, g, V, F)
     ctx.debug_occupy_cus(96, 400000)
-    time.sleep(0.01)
-    t0 = time.perf_counter()
+    time.sleep(0.05)
+    # times below are HIP-event times of the launches themselves (the host clock of a shared box proves nothing); the
+    # behaviour under test is in the device counters, the times only bound the polling
+    ctx.timing_reset()
+    ctx.timing_enable(True)
     ctx.aggregate(0, da.FORWARD)
     timeouts = ctx.get_option("spmm_gate_timeouts")         # (synchronises the compute stream only; the occupier sleeps on)
-    first = time.perf_counter() - t0
+    first_ms, n_first = ctx.timing_get("spmm")
     assert timeouts >= 1                                    # the sweep's workgroups were not co-resident: counted
-    assert first < 0.1                                      # bounded polling (round 2: 20 000 polls ~ 0.1 s per gate)
-    t0 = time.perf_counter()
+    assert n_first == 1 and first_ms < 100.0                # bounded polling: ~3 ms per timed-out gate class, not round 2's 0.1 s per gate
     for _ in range(6):                                      # inside the back-off: no gates, no new timeouts
         ctx.aggregate(0, da.FORWARD)
     assert ctx.get_option("spmm_gate_timeouts") == timeouts
-    later = (time.perf_counter() - t0) / 6
     assert ctx.get_option("spmm_ungated_launches") >= 6
-    assert later < first                                    # the timeout is not paid again on every launch
-    assert time.perf_counter() - t0 < 0.35                  # ... and all of it ran while the occupier held its CUs
+    all_ms, n_all = ctx.timing_get("spmm")
+    ctx.timing_enable(False)
+    assert n_all == 7 and (all_ms - first_ms) / 6 < 50.0    # ungated launches run at the unsynchronised rate, nobody polls
     assert np.array_equal(ctx.download(0, "ah"), ref)       # same bits whatever the placement (waits for the occupier)
     tot_ms, n = ctx.timing_get("spmm_gate_timeouts")        # the same counters through dory_timing_get
     assert n == timeouts and tot_ms >= 6
@@ -169,3 +171,59 @@ def test_loader_wave_same_bits_as_without_it(nb):
         ctx.close()
     assert rel_err(outs[1], ref) < 1e-5
     assert np.array_equal(outs[1], outs[0])
+
+
+@pytest.mark.timeout(300)
+def test_gate_backoff_ends_under_epoch_graph_replay():
+    """The back-off compares the context's K1s launch number with a horizon on the device.  As a kernel argument that
+    number was frozen into a recorded epoch (round 3): after one timeout during a replay every recorded launch stayed
+    ungated in all later replays.  It now lives on the device and the last workgroup of a launch bumps it, so replays
+    advance it: a timeout costs SWEEP_BACKOFF launches without gates, then the recorded launches gate again."""
+    import dorylus_amd as da
+    V, E = 60000, 1500000
+    g = _graph(V, E, 5)
+    ctx = da.Context(0)
+    ctx.configure(da.GCN, [128, 64, 8], V)
+    ctx.set_option("spmm_variant", 2)
+    ctx.set_option("spmm_blk_nb", 12)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    ctx.fill_uniform(0, "x", 3)
+    ctx.labels_upload(np.random.default_rng(1).integers(0, 8, V).astype(np.uint32))
+    ctx.weights_init_xavier()
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(1)                                              # eager: every lazily sized buffer exists
+    assert ctx.get_option("spmm_gate_timeouts") == 0
+    ctx.epoch_graph_begin()
+    _one_epoch(ctx, da)
+    ctx.epoch_graph_end()
+    ctx.epoch_graph_launch(2)
+    ctx.sync()
+    assert ctx.get_option("spmm_gate_timeouts") == 0 and ctx.get_option("spmm_ungated_launches") == 0
+    ctx.debug_occupy_cus(96, 300000)                        # a co-tenant holds 12 CUs per XCD while one epoch replays
+    time.sleep(0.05)
+    ctx.epoch_graph_launch(1)
+    timeouts = ctx.get_option("spmm_gate_timeouts")
+    assert timeouts >= 1
+    ctx.sync()                                              # the occupier is gone
+    ctx.epoch_graph_launch(12)                              # 3 K1s launches per epoch: far past the 16-launch back-off
+    u1 = ctx.get_option("spmm_ungated_launches")
+    ctx.epoch_graph_launch(6)
+    assert ctx.get_option("spmm_ungated_launches") == u1    # the recorded launches gate again
+    assert ctx.get_option("spmm_gate_timeouts") == timeouts
+    assert 1 <= u1 <= 2 * 17 + 3                            # (one back-off per class that timed out, plus the launch that did)
+    eng.close()
+    ctx.close()
+
+
+def _one_epoch(ctx, da):
+    """the stage calls of one 2-layer GCN epoch in Engine::runEpoch's order (what dory_engine_run issues)"""
+    ctx.aggregate(0, da.FORWARD)
+    ctx.apply_vertex(0, da.FORWARD)
+    ctx.aggregate(1, da.FORWARD)
+    ctx.apply_vertex(1, da.FORWARD)
+    ctx.weight_update(1)
+    ctx.aggregate(1, da.BACKWARD)
+    ctx.apply_vertex(0, da.BACKWARD)
+    ctx.weight_update(0)

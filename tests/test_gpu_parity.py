@@ -327,7 +327,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
     """P partitions as P contexts on one GPU; the transport between them is a host
     copy of the packed buffers (pack/unpack kernels + plan are the code under test)."""
     import torch
-    from dorylus_amd.halo import halo_plan
+    from halo_plan_ref import halo_plan
     from helpers import make_ctx
     P = len(gs)
     V = int(gs[0]["globalVtxCnt"])
