@@ -1,8 +1,9 @@
 /* dorylus_wire.h -- the byte formats of the reference's weight-server / Lambda protocol:
  * what a HIP graph server has to put on a ZeroMQ socket to talk to an UNMODIFIED Dorylus weight server, so that it can
- * join a mixed deployment.  Formats only -- the socket stays the caller's (this image has no ZeroMQ development
- * package); together with dory_comm_set_host_transport / dory_weight_get / dory_weight_grad_get / dory_weight_set
- * (dorylus_hip.h) this is the whole seam.  All little-endian, packed exactly as the reference writes them.
+ * join a mixed deployment.  Formats only -- the socket stays the caller's (the product library does not link ZeroMQ);
+ * together with dory_comm_set_host_transport / dory_weight_get / dory_weight_grad_get / dory_weight_set (dorylus_hip.h)
+ * this is the whole seam.  All little-endian, packed exactly as the reference writes them.  Exercised over real ZeroMQ
+ * sockets against a peer that reads the frames with the reference's own parse code: tests/test_wire_loopback.py.
  *
  *   chunk header   36 B  = u32 op | Chunk                (populateHeader(void*, op, Chunk&): commmanager/
  *                                                          message_service.cpp:2-6; HEADER_SIZE, common/utils.hpp:31)
