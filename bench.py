@@ -200,6 +200,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
         args.gpus = world
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -223,6 +224,19 @@ def main():
     preflight = None
     if world > 1:
         preflight = first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev)
+        # a hang inside the epochs of a first multi-GPU run (an exchange that never completes) must end with a message
+        # that says where, not with the driver's own kill: whole-run watchdog, generous against the ~1 min a run takes
+        import threading
+        run_stage = {"name": "setup (graph generation, partition build, upload)"}
+
+        def run_watchdog(limit=float(os.environ.get("DORY_BENCH_WATCHDOG_S", "1500"))):
+            time.sleep(limit)
+            sys.stderr.write("bench.py: rank %d still running after %.0f s, last stage: %s -- giving up\n" % (rank, limit, run_stage["name"]))
+            sys.stderr.flush()
+            os._exit(4)
+        threading.Thread(target=run_watchdog, daemon=True).start()
+    else:
+        run_stage = {"name": ""}
 
     global DIMS
     V, E_full, DIMS = WORKLOADS[args.workload]
@@ -275,6 +289,7 @@ def main():
             dist.broadcast(idt, 0)
             ctx.comm_init(idt.cpu().numpy(), rank, world)
     halo_ok = None
+    run_stage["name"] = "halo self-check (two exchanges + overlapped / sequential aggregates)"
     if world > 1 and not gat:
         flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -293,6 +308,7 @@ def main():
     # ---- N > 1: how many CUs do the exchange's kernels really take beside K1s?  Three extra warm-up epochs, one per
     # candidate reserve, smallest first; a reserve holds if no rank counted a gate timeout in its epoch ----
     reserve_probe = None
+    run_stage["name"] = "reserve probe (one epoch per candidate spmm_sweep_reserve_cus)"
     if world > 1 and not gat and ctx.get_option("spmm_variant") == 2 and not any(o.startswith("spmm_sweep_reserve_cus=") for o in args.opt):
         reserve_probe = {"tried": [], "chosen": None}
         for cand in (2, 4, 8):
@@ -312,6 +328,7 @@ def main():
         ctx.set_option("spmm_gates_rearm", 1)
 
     # ---- warmup, then exactly K timed steps ------------------------------------------
+    run_stage["name"] = "warm-up + timed epochs"
     if args.warmup:
         eng.run(args.warmup)
     ctx.timing_reset()
@@ -331,6 +348,7 @@ def main():
     else:
         E_in, E_out = nnz_in, nnz_out
     ms_per_step = elapsed * 1e3 / args.steps
+    run_stage["name"] = "bookkeeping after the timed region"
     nl = len(DIMS) - 1
     edges_per_epoch = nl * E_in + (nl - 1) * E_out           # L forward (CSC) + L-1 backward (CSR) aggregations
     tf_mode = (not gat) and ctx.transform_first_active()          # diagnostic: A(XW0) order, one more d1-wide CSR pass for dW0
@@ -550,7 +568,8 @@ def rank_of_8_epoch(da, workload, steps, warmup):
     what = {"amazon": "BASELINE config 4 (Amazon GCN 3-layer 300-64-64-25, 9.43 M vertices, 231.6 M edges) as rank 0 of 8 holds it",
             "friendster": "BASELINE config 5 (Friendster GCN 2-layer 256-48-51, 65.6 M vertices, 3.61 G edges) as rank 0 of 8 holds it"}[workload]
     res = extra_epoch(da, part, part.view(), "gcn", Vw, steps, warmup,
-                      what + ": uniform synthetic graph, only the records incident to the rank's block generated, compute only", dims=dims, ghosts=True)
+                      what + ": uniform synthetic graph, only the records incident to the rank's block generated, compute only", dims=dims, ghosts=True,
+                      pmc_key=workload + "_rank0of8")
     res["setup_s"] = round(time.time() - t0, 1)
     part.close()
     return res
@@ -641,7 +660,7 @@ def first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev):
     return res
 
 
-def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=False):
+def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=False, pmc_key=None):
     """one more configuration on one GPU: fresh context, same epoch loop, K timed steps after W warm-up steps"""
     import torch
     DIMS_ = dims or DIMS
@@ -689,13 +708,22 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
                         sum(nnz_out * ((DIMS_[l] + 31) // 32 * 32) for l in range(1, nl_)))
         t = fam["spmm"][0] / steps * 1e-3
         res["partition"] = {"local_vertices": N, "src_ghosts": Gs_, "dst_ghosts": Gd_, "in_edges": nnz_in, "out_edges": nnz_out}
+        traffic_, traffic_src_ = None, "no PMC pass on record for this configuration"
+        try:     # HBM-side bytes per epoch from the separate --pmc FETCH_SIZE pass (profiles/), for the kernel source it was collected for
+            ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(pmc_key or "", None)
+            if ent and ent.get("spmm_hip_blob") == git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip")):
+                traffic_, traffic_src_ = ent["fetch_bytes_per_epoch"], ent["source"]
+            elif ent:
+                traffic_src_ = "stale: collected for another spmm.hip -- re-run tools/collect_profiles.sh"
+        except (OSError, KeyError, ValueError):
+            pass
         res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": None,
+                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": traffic_, "traffic_source": traffic_src_,
+                           "traffic_what": "HBM-side FETCH bytes per epoch (five launches); algorithmic_bytes_per_epoch is the figure `achieved` uses",
                            "kernel": "spmm_rows_kernel<GROUP,CHUNKS> (K1 row gather; %d launches per epoch)" % (2 * nl_ - 1),
                            "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
                            "gathered_bytes_per_epoch": int(gathered), "gathered_TBps": round(gathered / t / 1e12, 3),
-                           "gathered_frac_of_achievable_hbm_6.3_TBps": round(gathered / t / 1e12 / 6.3, 4),
-                           "traffic_note": "HBM-side bytes of this configuration: profiles/r04_k1_amazon_rank_pmc_fetch_size.txt"}
+                           "gathered_frac_of_achievable_hbm_6.3_TBps": round(gathered / t / 1e12 / 6.3, 4)}
     if gnn == "gatmh" and fam["spmm"][1]:
         # compulsory bytes of the epoch's six edge passes (forward, destination-side and source-side backward sweeps of both
         # layers: 4 over the CSC, 2 over the CSR), each: the index stream once + pointers + one read and one write of an

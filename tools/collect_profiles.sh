@@ -25,6 +25,15 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_su
     rocprofv3 --pmc $set --kernel-trace -d /tmp/prof_${TAG}_set$i -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_set$i.log 2>&1
     python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_set$i -name '*.db' | head -1)" > "$OUT/${TAG}_pmc_set$i.txt" 2>&1
 done
+# config 4 as one rank of 8 holds it (K1 row gather, bench.py key amazon_rank0of8): kernel summary + HBM-side bytes
+rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_amz_k -o k -- python "$R/bench.py" --workload amazon --emulate 0/8 --steps 5 --warmup 1 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_amz_k.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_k -name '*.db' | head -1)" > "$OUT/${TAG}_k1_amazon_rank_kernel_stats.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_amz_f -o p -- python "$R/bench.py" --workload amazon --emulate 0/8 --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_amz_f.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_f -name '*.db' | head -1)" > "$OUT/${TAG}_k1_amazon_rank_pmc_fetch_size.txt" 2>&1
+# the community-ordered graph (bench.py --graph community): epoch + HBM-side bytes of its K1s launches
+python "$R/bench.py" --graph community --no-cpu-baseline --no-alt > "$OUT/${TAG}_bench_community.json" 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_com_f -o p -- python "$R/bench.py" --graph community --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_com_f.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_com_f -name '*.db' | head -1)" > "$OUT/${TAG}_community_pmc_fetch_size.txt" 2>&1
 cd "$R"
 python bench.py --gnn gat --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gat.json" 2>/dev/null
 python bench.py --gnn gatmh --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gatmh.json" 2>/dev/null
