@@ -546,6 +546,14 @@ def main():
         out["rmat"] = extra_epoch(da, part_r, part_r.view(), "gcn", V, steps_x, warm_x,
                                   "same GCN epoch on an R-MAT graph (a=.57 b=.19 c=.19, SURVEY 8d): same V and E, max degree ~8e5")
         del part_r
+        src, dst = synth_edges("community", V, E_target)
+        part_c = da.Partition.build(src, dst, np.zeros(V, np.int32), 0, 1)
+        del src, dst
+        out["community"] = extra_epoch(da, part_c, part_c.view(), "gcn", V, steps_x, warm_x,
+                                       "same GCN epoch on a graph with locality: 50 communities of consecutive ids, 85 % of the edges inside "
+                                       "(a METIS-ordered Reddit seen from the kernels).  K1s's even layout spreads the communities away by "
+                                       "construction; why a locality-keeping layout was not built: DESIGN.md section 3, round 4")
+        del part_c
         out["amazon_rank0of8"] = rank_of_8_epoch(da, "amazon", max(5, steps_x), warm_x)
         if args.with_friendster:
             out["friendster_rank0of8"] = rank_of_8_epoch(da, "friendster", max(5, steps_x), warm_x)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Round 4, experiment 1: K1s with 20 waves per CU (96 registers, 8 rows per lane group) against the product form (one
 1024-thread workgroup, 16 waves, 10 rows).  First as two 640-thread workgroups per CU (never co-resident: residency_probe),
-then as five 256-thread workgroups per CU, with and without the loader wave.  GPU box only.
+then as five 256-thread workgroups per CU, with and without the loader wave, then as one 768-thread workgroup with 20 rows.
+NOT RUNNABLE ON THE PRODUCT BUILD: it needs the option `spmm_sweep_threads` of profiles/r04_k1s_wg_threads_experiment.patch
+(apply it to csrc/spmm.hip, ctx.hpp, abi_stages.hip, abi_context.hip, host/sweep_deal.cpp of commit c603f01 and rebuild);
+results: profiles/r04_k1s_wg_threads_ab.txt, profiles/r04_experiments.txt item 1.  GPU box only.
   python tools/experiments/k1s_threads_ab.py            # correctness on a partition with ghost rows, then timing A/B"""
 import os
 import sys
