@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_bench_multirank_dry_run_on_one_gpu(world):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
