@@ -187,6 +187,8 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
     c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
+    c->opt["gatmh_el_on_the_fly"] = 1;       // multi-head GAT, blocked forward with fused statistics, heads of <= 16 features: el[src] from the gathered row instead of a second gather
+    c->opt["gatmh_fused_stats"] = 1;         // multi-head GAT, blocked forward: online softmax per source block + merge in the reduce (0: separate statistics pass first)
     c->opt["gcn_cache_ah0"] = 0;         // GCN: keep ah@0 = A_hat x across epochs while x, fg@0 and the adjacency are unchanged (opt-in; the reference recomputes it)
     c->opt["gcn_transform_first"] = 0;   // GCN layers as A(XW) instead of (AX)W where the input is wider than the output: 1 = layer 0, 2 = all (see tf_layer)
     c->opt["epoch_graph"] = 0;       // engine: replay a recorded epoch (hipGraph) when the partition is alone

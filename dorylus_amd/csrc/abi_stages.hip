@@ -309,10 +309,20 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                                      (D % 4 == 0 || K == 1) &&
                                      (size_t)c->blkIn.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
                 NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el");
-                if (blocked)
+                if (blocked) {
+                    // "gatmh_fused_stats" (default 1): the blocks' own online softmax + a merge in the reduce kernel instead
+                    // of a statistics pass over all edges first; the blocks' (m_b, den_b) live in the scratch buffer
+                    float *stat_partial = nullptr;
+                    if (c->opt["gatmh_fused_stats"]) {
+                        int src_ = ensure_scratch(c, (size_t)2 * c->blkIn.nb * c->N * el->ld * sizeof(float));
+                        if (src_) return src_;
+                        stat_partial = c->scratch;
+                    }
                     HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->blkIn, z->d,
                                                           fgz->d, el->d, fgel->d, er->d, o->d, m->d, den->d, c->partial,
-                                                          c->Gsrc > 0, c->compute));
+                                                          c->Gsrc > 0, c->compute, stat_partial,
+                                                          c->opt["gatmh_el_on_the_fly"] ? c->weights[fl]["a_l"].d : nullptr));
+                }
                 else if (c->numNodes > 1)
                     return fail(c, DORY_ERR_ARG, "multi-head GAT: a partitioned run needs the source-blocked kernels (gatmh_blocked = 1, K*D a shape they cover)");
                 else
@@ -354,7 +364,8 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 Timed t(c, "spmm", c->compute);
                 HIPCK(c, launch_gatmh_backward_blocked_dst(c->N, K, D, z->ld, el->ld, c->blkIn, z->d, fgz->d, el->d, fgel->d,
                                                            er->d, m->d, den->d, dO->d, tt->d, der->d, c->partial, st4, lds4,
-                                                           c->Gsrc > 0, c->compute));
+                                                           c->Gsrc > 0, c->compute,
+                                                           c->opt["gatmh_el_on_the_fly"] ? c->weights[fl]["a_l"].d : nullptr));
             }
             if (phase == 1) return DORY_OK;
             if (phase == 0 && c->numNodes > 1) {   // ghost destinations of the out-edges: their dO and st rows

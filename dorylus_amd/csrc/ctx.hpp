@@ -322,7 +322,9 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
                                         const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
                                         const float *z, const float *zg /*ghost rows (ids >= N) or nullptr*/,
                                         const float *el, const float *elg, const float *er, float *o, float *m,
-                                        float *den, float *partial /*nb x N x ld*/, bool ghosts, hipStream_t s);
+                                        float *den, float *partial /*nb x N x ld*/, bool ghosts, hipStream_t s,
+                                        float *stat_partial = nullptr /*2 x nb x N x ldk floats: online softmax per block, no statistics pass*/,
+                                        const float *a_l = nullptr /*K x D: source scores formed from the gathered rows*/);
 // source-blocked backward in two phases (a partitioned run exchanges the ghost rows of dO and st4 in between):
 // dst = t, der, st4 = (er, m, 1/den, t) per local (v,k); src = del, dz.  lds4: float4 stride of the st4 rows.
 bool gatmh_backward_blocked_ok(uint32_t K, uint32_t D, uint32_t ld);
@@ -330,7 +332,8 @@ hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D,
                                              const BlockedAdj &Bin, const float *z, const float *zg, const float *el,
                                              const float *elg, const float *er, const float *m, const float *den,
                                              const float *d_o, float *t, float *der, float *partial, float4 *st4,
-                                             uint32_t lds4, bool ghosts, hipStream_t s);
+                                             uint32_t lds4, bool ghosts, hipStream_t s,
+                                             const float *a_l = nullptr /*K x D: source scores formed from the gathered rows*/);
 hipError_t launch_gatmh_backward_blocked_src(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk,
                                              const BlockedAdj &Bout, const float *z, const float *el, const float *d_o,
                                              const float *dog, const float4 *st4, const float4 *stg, uint32_t lds4,

@@ -61,12 +61,35 @@ __global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const flo
 
 constexpr int GATMH_BLK_ROWS = 64;   // destination rows per workgroup (as K1b)
 
-template <int GROUP, bool GH>
+// sum over the HL neighbouring lanes of a head (first two butterfly steps by DPP inside a quad: see the backward kernels)
+__device__ __forceinline__ float dpp_quad(float v, int ctrl_b1_or_4e) {
+    return ctrl_b1_or_4e == 0xB1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true))
+                                 : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float head_lanes_sum(float v, int HL) {
+    if (HL >= 2) v += dpp_quad(v, 0xB1);
+    if (HL >= 4) v += dpp_quad(v, 0x4E);
+    for (int o = 4; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+
+// ONLINE (round 4, the default): no statistics pass at all.  Every (block, row) segment runs its own online softmax --
+// running maximum m_b, acc and den rescaled by exp(m_old - m_new) when it moves -- and leaves (m_b, den_b) per head
+// beside its unnormalised partial row; the reduce kernel merges the blocks (exp(m_b - m) weights, block order) and the
+// self edge, normalises, and writes m and den for the backward sweeps.  The separate pass cost 2.4 of 30 ms per epoch
+// for 32 B per edge of gathers whose only product were two floats per (vertex, head).
+// ELFLY: the source's score el[u,k] = <Z[u,k,:], a_l[k,:]> is formed from the row the lane has just gathered (4-term dot +
+// two DPP adds inside the head's quad) instead of a second, 4-byte gather per entry and lane: heads of at most 16 features
+// (one quad of float4 lanes).  Same function as gatmh_scores_kernel's el to summation order.
+template <int GROUP, bool GH, bool ONLINE, bool ELFLY>
 __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
                                                                     const float *zg, const float *el,
                                                                     const float *elg, const float *er,
                                                                     const float *m_in, const float *den_in,
-                                                                    float *partial, uint32_t tiles, uint32_t rounds) {
+                                                                    float *partial, uint32_t tiles, uint32_t rounds,
+                                                                    float *pm /*[nb][N][ldk]*/, float *pden,
+                                                                    const float *a_l /*K x D, ELFLY*/) {
     constexpr int RPW = 64 / GROUP;
     constexpr int BLK_ITER = GATMH_BLK_ROWS / (4 * RPW);
     const uint32_t id = blockIdx.x;
@@ -91,6 +114,12 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
     float4 *p4 = reinterpret_cast<float4 *>(partial) + (size_t)b * a.N * nchunk;
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
+    float4 al4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int HL = (int)(a.D >> 2);                       // lanes per head (ELFLY: 1, 2 or 4)
+    if constexpr (ELFLY) { if (col_ok) al4 = reinterpret_cast<const float4 *>(a_l)[ccol]; }
+    auto el_of = [&](const float4 &x) -> float {          // ELFLY: this lane's head's score of the gathered row
+        return head_lanes_sum(fmaf(x.x, al4.x, fmaf(x.y, al4.y, fmaf(x.z, al4.z, x.w * al4.w))), HL);
+    };
 #pragma unroll 1
     for (int it = 0; it < BLK_ITER; ++it) {
         const uint32_t v = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
@@ -98,9 +127,30 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
         const uint32_t vv = row_ok ? v : 0;
         uint64_t e = row_ok ? base + boff[v] : 0;
         const uint64_t end = row_ok ? base + boff[v + 1] : 0;
-        const float er_v = er[(size_t)vv * a.ldk + k], m_v = m_in[(size_t)vv * a.ldk + k];
-        const float idn = 1.f / den_in[(size_t)vv * a.ldk + k];
+        const float er_v = er[(size_t)vv * a.ldk + k];
+        float m_v = -INFINITY, idn = 1.f, den = 0.f;
+        if constexpr (!ONLINE) {
+            m_v = m_in[(size_t)vv * a.ldk + k];
+            idn = 1.f / den_in[(size_t)vv * a.ldk + k];
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // one entry: ONLINE moves the running maximum first (acc and den follow it), then adds exp(s - m) * x
+        auto add_entry = [&](float el_s, const float4 &x) {
+            const float sc = lrelu02(el_s + er_v);
+            float al;
+            if constexpr (ONLINE) {
+                const float mn = fmaxf(m_v, sc);
+                const float f = __expf(m_v - mn);          // (exp(-inf) = 0 on the first entry: acc and den are 0 anyway)
+                al = __expf(sc - mn);
+                acc.x *= f; acc.y *= f; acc.z *= f; acc.w *= f;
+                den = fmaf(den, f, al);
+                m_v = mn;
+            } else {
+                al = __expf(sc - m_v) * idn;
+            }
+            acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
+            acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+        };
         while (e < end) {
             const int n = (end - e) < (uint64_t)GROUP ? (int)(end - e) : GROUP;
             uint32_t my_idx = 0;
@@ -113,33 +163,43 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = (uint32_t)__shfl((int)my_idx, j + u, GROUP);
                     x[u] = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
-                    w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
+                    if constexpr (!ELFLY) w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float al = __expf(lrelu02(w[u] + er_v) - m_v) * idn;
-                    acc.x = fmaf(al, x[u].x, acc.x); acc.y = fmaf(al, x[u].y, acc.y);
-                    acc.z = fmaf(al, x[u].z, acc.z); acc.w = fmaf(al, x[u].w, acc.w);
-                }
+                for (int u = 0; u < 4; ++u) add_entry(ELFLY ? el_of(x[u]) : w[u], x[u]);
             }
             for (; j < n; ++j) {
                 const uint32_t s = (uint32_t)__shfl((int)my_idx, j, GROUP);
                 const float4 x = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
-                const float el_s = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
-                const float al = __expf(lrelu02(el_s + er_v) - m_v) * idn;
-                acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
-                acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+                float el_s;
+                if constexpr (ELFLY) el_s = el_of(x);
+                else el_s = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
+                add_entry(el_s, x);
             }
             e += n;
         }
-        if (row_ok && col_ok) nt_store4(p4 + (size_t)v * nchunk + col, acc);
+        if (row_ok && col_ok) {
+            nt_store4(p4 + (size_t)v * nchunk + col, acc);
+            if constexpr (ONLINE) {   // the first float4 of a head carries its statistics (every lane of a head holds the same pair)
+                if ((ccol * 4) % a.D < 4 || a.K == 1) {
+                    const size_t o_ = ((size_t)b * a.N + v) * a.ldk + k;
+                    pm[o_] = m_v;
+                    pden[o_] = den;
+                }
+            }
+        }
     }
 }
 
 // o[v,:] = sum_b partial[b][v,:] + alpha_self * z[v,:]
+// ONLINE: the blocks' partial rows are unnormalised sums against their own maxima m_b: o = (sum_b exp(m_b - m) partial_b +
+// exp(s_self - m) z_v) / (sum_b exp(m_b - m) den_b + exp(s_self - m)), m = max(max_b m_b, s_self); m and den are written
+// here (the backward sweeps read them).  Block order, like the plain sum.
+template <bool ONLINE>
 __global__ __launch_bounds__(256) void gatmh_forward_reduce_kernel(GatMhArgs a, uint32_t nb, const float *partial,
                                                                    const float *z, const float *el, const float *er,
-                                                                   const float *m_in, const float *den_in, float *o) {
+                                                                   float *m_io, float *den_io, float *o,
+                                                                   const float *pm, const float *pden) {
     const uint32_t nchunk = a.ld >> 2;
     const size_t n = (size_t)a.N * nchunk;
     const float4 *p4 = reinterpret_cast<const float4 *>(partial);
@@ -150,15 +210,35 @@ __global__ __launch_bounds__(256) void gatmh_forward_reduce_kernel(GatMhArgs a, 
         if (col * 4 >= a.K * a.D) continue;
         const uint32_t k = min((col * 4) / a.D, a.K - 1);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t b = 0; b < nb; ++b) {
-            const float4 p = nt_load4(p4 + (size_t)b * n + i);
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
         const size_t vk = (size_t)v * a.ldk + k;
-        const float al = __expf(lrelu02(el[vk] + er[vk]) - m_in[vk]) / den_in[vk];   // the self edge
         const float4 x = z4[i];
-        acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
-        acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+        if constexpr (ONLINE) {
+            const float s_self = lrelu02(el[vk] + er[vk]);
+            const size_t nk = (size_t)a.N * a.ldk;
+            float m = s_self;
+            for (uint32_t b = 0; b < nb; ++b) m = fmaxf(m, pm[(size_t)b * nk + vk]);
+            float den = 0.f;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const float f = __expf(pm[(size_t)b * nk + vk] - m);          // an empty segment left m_b = -inf: weight 0
+                const float4 p = nt_load4(p4 + (size_t)b * n + i);
+                acc.x = fmaf(f, p.x, acc.x); acc.y = fmaf(f, p.y, acc.y); acc.z = fmaf(f, p.z, acc.z); acc.w = fmaf(f, p.w, acc.w);
+                den = fmaf(f, pden[(size_t)b * nk + vk], den);
+            }
+            const float fs = __expf(s_self - m);
+            den += fs;
+            acc.x = fmaf(fs, x.x, acc.x); acc.y = fmaf(fs, x.y, acc.y); acc.z = fmaf(fs, x.z, acc.z); acc.w = fmaf(fs, x.w, acc.w);
+            const float idn = 1.f / den;
+            acc.x *= idn; acc.y *= idn; acc.z *= idn; acc.w *= idn;
+            if ((col * 4) % a.D < 4 || a.K == 1) { m_io[vk] = m; den_io[vk] = den; }
+        } else {
+            for (uint32_t b = 0; b < nb; ++b) {
+                const float4 p = nt_load4(p4 + (size_t)b * n + i);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            const float al = __expf(lrelu02(el[vk] + er[vk]) - m_io[vk]) / den_io[vk];   // the self edge
+            acc.x = fmaf(al, x.x, acc.x); acc.y = fmaf(al, x.y, acc.y);
+            acc.z = fmaf(al, x.z, acc.z); acc.w = fmaf(al, x.w, acc.w);
+        }
         o4[i] = acc;
     }
 }
@@ -167,12 +247,19 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
                                         const uint64_t *colptr, const uint32_t *rowidx, const BlockedAdj &B,
                                         const float *z, const float *zg, const float *el, const float *elg,
                                         const float *er, float *o, float *m, float *den, float *partial, bool ghosts,
-                                        hipStream_t s) {
+                                        hipStream_t s, float *stat_partial /* 2 x nb x N x ldk floats: the blocks' (m_b, den_b);
+                                        nullptr = separate statistics pass first (round 1-3 form) */,
+                                        const float *a_l /* K x D attention vector: scores of the sources formed from the gathered
+                                        rows (heads of <= 16 features, 32-lane launches); nullptr = gather el */) {
     if (N == 0) return hipSuccess;
     if (!gatmh_shape_ok(K, D) || ((D & 3) && K != 1) || (ld & 3) || B.nb == 0) return hipErrorInvalidValue;
     GatMhArgs a{N, K, D, ld, ldk, colptr, rowidx};
-    if (ghosts) hipLaunchKernelGGL(gatmh_stats_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
-    else hipLaunchKernelGGL(gatmh_stats_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
+    const bool online = stat_partial != nullptr;
+    float *pm = stat_partial, *pden = online ? stat_partial + (size_t)B.nb * N * ldk : nullptr;
+    if (!online) {
+        if (ghosts) hipLaunchKernelGGL(gatmh_stats_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
+        else hipLaunchKernelGGL(gatmh_stats_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, s, a, el, elg, er, m, den);
+    }
     const uint32_t nchunk = ld >> 2;
     const int group = ld >= 128 ? 32 : 16;
     const uint32_t slabs = (((K * D + 3) >> 2) + group - 1) / group;
@@ -180,17 +267,26 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
     const uint64_t grid = (uint64_t)slabs * rounds * tiles * 8;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
 #define GATMH_FWD(G, H)                                                                                                  \
-    hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, el, elg, er, \
-                       m, den, partial, tiles, rounds)
-    if (group == 32 && ghosts) GATMH_FWD(32, true);
+    do {                                                                                                                 \
+        if (online) hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H, true, false>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, \
+                                       el, elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);                      \
+        else hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H, false, false>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, el,   \
+                                elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);                                 \
+    } while (0)
+    const bool elfly = a_l != nullptr && online && group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
+    if (elfly && ghosts) hipLaunchKernelGGL((gatmh_forward_blocked_kernel<32, true, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg,
+                                            el, elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);
+    else if (elfly) hipLaunchKernelGGL((gatmh_forward_blocked_kernel<32, false, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg,
+                                       el, elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);
+    else if (group == 32 && ghosts) GATMH_FWD(32, true);
     else if (group == 32) GATMH_FWD(32, false);
     else if (ghosts) GATMH_FWD(16, true);
     else GATMH_FWD(16, false);
 #undef GATMH_FWD
     const size_t n = (size_t)N * nchunk;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(gatmh_forward_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den,
-                       o);
+    if (online) hipLaunchKernelGGL(gatmh_forward_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den, o, pm, pden);
+    else hipLaunchKernelGGL(gatmh_forward_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den, o, pm, pden);
     return hipGetLastError();
 }
 
@@ -201,24 +297,13 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
 // partial dZ rows and partial del; small reduce kernels add the blocks in order, then the self edge.
 // sum over the HL neighbouring lanes of a head.  The first two butterfly steps stay inside a quad: DPP quad_perm
 // ([1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E) moves the operand in the VALU instead of a ds_bpermute round trip through LDS
-__device__ __forceinline__ float dpp_quad(float v, int ctrl_b1_or_4e) {
-    return ctrl_b1_or_4e == 0xB1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true))
-                                 : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float head_lanes_sum(float v, int HL) {
-    if (HL >= 2) v += dpp_quad(v, 0xB1);
-    if (HL >= 4) v += dpp_quad(v, 0x4E);
-    for (int o = 4; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <int GROUP, bool GH>
+template <int GROUP, bool GH, bool ELFLY /* el[src] from the gathered row (forward kernel above) */>
 __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
                                                                     const float *zg, const float *el,
                                                                     const float *elg, const float *er,
                                                                     const float *m_in, const float *den_in,
                                                                     const float *d_o, float4 *pst /*[nb][N][K]*/,
-                                                                    uint32_t tiles, uint32_t rounds, int HL) {
+                                                                    uint32_t tiles, uint32_t rounds, int HL, const float *a_l) {
     constexpr int RPW = 64 / GROUP;
     constexpr int BLK_ITER = GATMH_BLK_ROWS / (4 * RPW);
     const uint32_t id = blockIdx.x;
@@ -243,6 +328,8 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
     const float4 *do4 = reinterpret_cast<const float4 *>(d_o);
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
+    float4 al4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (ELFLY) { if (col_ok) al4 = reinterpret_cast<const float4 *>(a_l)[ccol]; }
 #pragma unroll 1
     for (int it = 0; it < BLK_ITER; ++it) {
         const uint32_t v = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
@@ -267,13 +354,15 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
                     const int jj = j + u < n ? j + u : n - 1;      // dead slots repeat the last edge, weight 0 below
                     const uint32_t s = (uint32_t)__shfl((int)my_idx, jj, GROUP);
                     x[u] = ((!GH || s < a.N) ? z4 + (size_t)s * nchunk : zg4 + (size_t)(s - a.N) * nchunk)[ccol];
-                    w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
+                    if constexpr (!ELFLY) w[u] = (!GH || s < a.N) ? el[(size_t)s * a.ldk + k] : elg[(size_t)(s - a.N) * a.ldk + k];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float da = dv.x * x[u].x;
                     da = fmaf(dv.y, x[u].y, da); da = fmaf(dv.z, x[u].z, da); da = fmaf(dv.w, x[u].w, da);
                     da = head_lanes_sum(da, HL);
+                    if constexpr (ELFLY)
+                        w[u] = head_lanes_sum(fmaf(x[u].x, al4.x, fmaf(x[u].y, al4.y, fmaf(x[u].z, al4.z, x[u].w * al4.w))), HL);
                     const float pre = w[u] + er_v;
                     const float al = j + u < n ? __expf(lrelu02(pre) - m_v) * idn : 0.f;
                     const float lp = pre > 0.f ? 1.f : GATMH_SLOPE;
@@ -479,7 +568,7 @@ hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D,
                                              const BlockedAdj &Bin, const float *z, const float *zg, const float *el,
                                              const float *elg, const float *er, const float *m, const float *den,
                                              const float *d_o, float *t, float *der, float *partial, float4 *st4,
-                                             uint32_t lds4, bool ghosts, hipStream_t s) {
+                                             uint32_t lds4, bool ghosts, hipStream_t s, const float *a_l) {
     if (N == 0) return hipSuccess;
     GatMhBwdPlan p;
     if (!gatmh_bwd_plan(N, K, D, ld, &p) || Bin.nb == 0) return hipErrorInvalidValue;
@@ -489,9 +578,14 @@ hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D,
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
     float4 *pst = reinterpret_cast<float4 *>(partial);
 #define GATMH_DST(G, H)                                                                                                  \
-    hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<G, H>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,  \
-                       er, m, den, d_o, pst, p.tiles, rounds, p.HL)
-    if (p.group == 32 && ghosts) GATMH_DST(32, true);
+    hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<G, H, false>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,  \
+                       er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l)
+    const bool elfly = a_l != nullptr && p.group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
+    if (elfly && ghosts) hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<32, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,
+                                            er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l);
+    else if (elfly) hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<32, false, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,
+                                       er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l);
+    else if (p.group == 32 && ghosts) GATMH_DST(32, true);
     else if (p.group == 32) GATMH_DST(32, false);
     else if (ghosts) GATMH_DST(16, true);
     else GATMH_DST(16, false);
