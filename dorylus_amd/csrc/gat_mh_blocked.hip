@@ -62,26 +62,25 @@ __global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const flo
 constexpr int GATMH_BLK_ROWS = 64;   // destination rows per workgroup (as K1b)
 
 // sum over the HL neighbouring lanes of a head (first two butterfly steps by DPP inside a quad: see the backward kernels)
-__device__ __forceinline__ float dpp_quad(float v, int ctrl_b1_or_4e) {
-    return ctrl_b1_or_4e == 0xB1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true))
-                                 : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+// All inside the VALU: quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E) for the first two butterfly steps, then
+// row_half_mirror (0x141: lane i <-> 7 - i of its 8 lanes) and row_mirror (0x140: lane i <-> 15 - i of its 16-lane DPP row)
+// -- after the quad steps every lane of a quad holds the quad's total, so a mirror reaches "the other quad / the other half"
+// as well as an xor would.  Only a head wider than 16 lanes (a single head on a 32-lane slab) still needs ds_bpermute.
+// Lane groups of 16 are DPP rows (lane / 16), so this covers the single-head 64-float layer entirely (round 4; it used two
+// ds_bpermute round trips through the LDS crossbar per entry before).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float head_lanes_sum(float v, int HL) {
-    if (HL >= 2) v += dpp_quad(v, 0xB1);
-    if (HL >= 4) v += dpp_quad(v, 0x4E);
-    for (int o = 4; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (HL >= 2) v += dpp_mov<0xB1>(v);
+    if (HL >= 4) v += dpp_mov<0x4E>(v);
+    if (HL >= 8) v += dpp_mov<0x141>(v);
+    if (HL >= 16) v += dpp_mov<0x140>(v);
+    for (int o = 16; o < HL; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-
-// ONLINE (round 4, the default): no statistics pass at all.  Every (block, row) segment runs its own online softmax --
-// running maximum m_b, acc and den rescaled by exp(m_old - m_new) when it moves -- and leaves (m_b, den_b) per head
-// beside its unnormalised partial row; the reduce kernel merges the blocks (exp(m_b - m) weights, block order) and the
-// self edge, normalises, and writes m and den for the backward sweeps.  The separate pass cost 2.4 of 30 ms per epoch
-// for 32 B per edge of gathers whose only product were two floats per (vertex, head).
-// ELFLY: the source's score el[u,k] = <Z[u,k,:], a_l[k,:]> is formed from the row the lane has just gathered (4-term dot +
-// two DPP adds inside the head's quad) instead of a second, 4-byte gather per entry and lane: heads of at most 16 features
-// (one quad of float4 lanes).  Same function as gatmh_scores_kernel's el to summation order.
 template <int GROUP, bool GH, bool ONLINE, bool ELFLY>
 __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a, BlockedAdj B, const float *z,
                                                                     const float *zg, const float *el,
@@ -115,8 +114,11 @@ __global__ __launch_bounds__(256) void gatmh_forward_blocked_kernel(GatMhArgs a,
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
     float4 al4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int HL = (int)(a.D >> 2);                       // lanes per head (ELFLY: 1, 2 or 4)
-    if constexpr (ELFLY) { if (col_ok) al4 = reinterpret_cast<const float4 *>(a_l)[ccol]; }
+    const int HL = a.K == 1 ? GROUP : (int)(a.D >> 2);    // lanes per head (ELFLY: 1, 2, 4, or the 16 of a single-head row)
+    if constexpr (ELFLY) {   // a_l is a dense K x D vector: the last float4 of a 41-feature head is read element by element
+        const uint32_t f0 = ccol * 4, KD = a.K * a.D;
+        if (col_ok) al4 = make_float4(a_l[f0], f0 + 1 < KD ? a_l[f0 + 1] : 0.f, f0 + 2 < KD ? a_l[f0 + 2] : 0.f, f0 + 3 < KD ? a_l[f0 + 3] : 0.f);
+    }
     auto el_of = [&](const float4 &x) -> float {          // ELFLY: this lane's head's score of the gathered row
         return head_lanes_sum(fmaf(x.x, al4.x, fmaf(x.y, al4.y, fmaf(x.z, al4.z, x.w * al4.w))), HL);
     };
@@ -273,16 +275,22 @@ hipError_t launch_gatmh_forward_blocked(uint32_t N, uint32_t K, uint32_t D, uint
         else hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H, false, false>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, el,   \
                                 elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);                                 \
     } while (0)
-    const bool elfly = a_l != nullptr && online && group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
-    if (elfly && ghosts) hipLaunchKernelGGL((gatmh_forward_blocked_kernel<32, true, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg,
-                                            el, elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);
-    else if (elfly) hipLaunchKernelGGL((gatmh_forward_blocked_kernel<32, false, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg,
-                                       el, elg, er, m, den, partial, tiles, rounds, pm, pden, a_l);
+    // el from the gathered row: heads of one quad of lanes (D <= 16) on 32-lane slabs, or the single head of a one-slab 16-lane row
+    const bool elfly32 = a_l != nullptr && online && group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
+    const bool elfly16 = a_l != nullptr && online && group == 16 && K == 1 && slabs == 1;
+#define GATMH_FWD_EL(G, H)                                                                                               \
+    hipLaunchKernelGGL((gatmh_forward_blocked_kernel<G, H, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, B, z, zg, el, elg, \
+                       er, m, den, partial, tiles, rounds, pm, pden, a_l)
+    if (elfly32 && ghosts) GATMH_FWD_EL(32, true);
+    else if (elfly32) GATMH_FWD_EL(32, false);
+    else if (elfly16 && ghosts) GATMH_FWD_EL(16, true);
+    else if (elfly16) GATMH_FWD_EL(16, false);
     else if (group == 32 && ghosts) GATMH_FWD(32, true);
     else if (group == 32) GATMH_FWD(32, false);
     else if (ghosts) GATMH_FWD(16, true);
     else GATMH_FWD(16, false);
 #undef GATMH_FWD
+#undef GATMH_FWD_EL
     const size_t n = (size_t)N * nchunk;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     if (online) hipLaunchKernelGGL(gatmh_forward_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, a, B.nb, partial, z, el, er, m, den, o, pm, pden);
@@ -329,7 +337,10 @@ __global__ __launch_bounds__(256) void gatmh_bwd_dst_blocked_kernel(GatMhArgs a,
     const uint32_t *boff = B.boff + (size_t)b * (a.N + 1);
     const uint64_t base = B.bbase[b];
     float4 al4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (ELFLY) { if (col_ok) al4 = reinterpret_cast<const float4 *>(a_l)[ccol]; }
+    if constexpr (ELFLY) {
+        const uint32_t f0 = ccol * 4, KD = a.K * a.D;
+        if (col_ok) al4 = make_float4(a_l[f0], f0 + 1 < KD ? a_l[f0 + 1] : 0.f, f0 + 2 < KD ? a_l[f0 + 2] : 0.f, f0 + 3 < KD ? a_l[f0 + 3] : 0.f);
+    }
 #pragma unroll 1
     for (int it = 0; it < BLK_ITER; ++it) {
         const uint32_t v = tile * GATMH_BLK_ROWS + (uint32_t)((it * 4 + wave) * RPW + gi);
@@ -580,16 +591,21 @@ hipError_t launch_gatmh_backward_blocked_dst(uint32_t N, uint32_t K, uint32_t D,
 #define GATMH_DST(G, H)                                                                                                  \
     hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<G, H, false>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,  \
                        er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l)
-    const bool elfly = a_l != nullptr && p.group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
-    if (elfly && ghosts) hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<32, true, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,
-                                            er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l);
-    else if (elfly) hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<32, false, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,
-                                       er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l);
+    const bool elfly32 = a_l != nullptr && p.group == 32 && K > 1 && (D == 4 || D == 8 || D == 16);
+    const bool elfly16 = a_l != nullptr && p.group == 16 && K == 1 && p.slabs == 1;
+#define GATMH_DST_EL(G, H)                                                                                               \
+    hipLaunchKernelGGL((gatmh_bwd_dst_blocked_kernel<G, H, true>), dim3((uint32_t)grid), dim3(256), 0, s, a, Bin, z, zg, el, elg,   \
+                       er, m, den, d_o, pst, p.tiles, rounds, p.HL, a_l)
+    if (elfly32 && ghosts) GATMH_DST_EL(32, true);
+    else if (elfly32) GATMH_DST_EL(32, false);
+    else if (elfly16 && ghosts) GATMH_DST_EL(16, true);
+    else if (elfly16) GATMH_DST_EL(16, false);
     else if (p.group == 32 && ghosts) GATMH_DST(32, true);
     else if (p.group == 32) GATMH_DST(32, false);
     else if (ghosts) GATMH_DST(16, true);
     else GATMH_DST(16, false);
 #undef GATMH_DST
+#undef GATMH_DST_EL
     hipLaunchKernelGGL(gatmh_bwd_dst_reduce_kernel, dim3(p.nk_blocks), dim3(256), 0, s, a, Bin.nb, pst, z, el, er, m, den, d_o,
                        t, der, st4, lds4);
     return hipGetLastError();
