@@ -89,8 +89,11 @@ def test_gat_mh_rejects_bad_shapes():
     ctx.close()
 
 
+@pytest.mark.parametrize("dims,heads", [([24, 64, 6], [4, 1]),      # 16-lane slabs: 4 heads x 16, then one head of 6
+                                        ([24, 128, 6], [8, 1])])     # the Reddit layer shape, 8 heads x 16 on a 32-lane slab: the
+                                                                     # ghost-row instantiations of the el-from-the-row kernels
 @pytest.mark.parametrize("P", [2, 4])
-def test_gat_mh_partitioned_epoch_vs_oracle(P):
+def test_gat_mh_partitioned_epoch_vs_oracle(P, dims, heads):
     """P partitions (one context each, ghost rows moved by pack / unpack + a device copy, i.e. everything of the
     multi-GPU path but RCCL itself): forward exchange of z, scores of the ghost sources recomputed locally, the
     backward sweep in its two phases with dO and st shipped in between -- against the single-partition float64 oracle."""
@@ -100,7 +103,7 @@ def test_gat_mh_partitioned_epoch_vs_oracle(P):
     import partition_oracle as po
     from halo_plan_ref import halo_plan
     from helpers import rel_err
-    dims, heads, V, E = [24, 64, 6], [4, 1], 240, 2600
+    V, E = 240, 2600
     rng = np.random.default_rng(17)
     s, d = rng.integers(0, V, E), rng.integers(0, V, E)
     parts = (rng.permutation(V) % P).astype(np.int64)                 # scattered ownership: many ghosts
