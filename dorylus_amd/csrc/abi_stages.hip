@@ -22,7 +22,10 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         // K1b pays nb partial rows per output row: only worth it (and only affordable: the
         // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
         // hundred L2 windows at most.  Larger partitions keep K1.
-        const uint64_t window = 0;   // K1b's own windows (K1s has its own layout: ensure_sweep)
+        // K1b's own windows (K1s has its own layout: ensure_sweep).  The multi-head GAT sweeps pay more per partial row than
+        // K1b does (statistics beside every partial, three sweeps per layer): 1.5 x the window = 16 blocks instead of 24 at
+        // Reddit size (27.4 -> 26.8-27.0 ms per epoch; 8 blocks: 32.0, 32: 29.2 -- profiles/r04_experiments.txt item 8d)
+        const uint64_t window = c->gnn == DORY_GATMH ? ((uint32_t)group * 16u >= 512u ? (uint64_t)7864320u : (uint64_t)5898240u) : 0;
         const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u, window);
         // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
         // K1 then gathers from L2 without partial sums or a second kernel
