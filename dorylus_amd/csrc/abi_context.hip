@@ -216,6 +216,9 @@ static void free_graph(dory_ctx *c) {
     }
     free_blocked(&c->blkIn);
     free_blocked(&c->blkOut);
+    free_blocked(&c->blkIn16);
+    free_blocked(&c->blkOut16);
+    c->blkIn16_built = c->blkOut16_built = false;
     free_blocked(&c->swpIn);
     free_blocked(&c->swpOut);
     c->swpIn_built = c->swpOut_built = c->swpIn_na = c->swpOut_na = false;
@@ -511,8 +514,15 @@ int dory_preallocate(dory_ctx *c) {
         for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
         if ((rc = ensure_blocked(c, true, blk_group_for(c, maxld)))) return rc;
         if ((rc = ensure_blocked(c, false, blk_group_for(c, maxld)))) return rc;   // backward, source side
+        uint32_t minld = maxld;
+        for (uint32_t l = 0; l < L; ++l) minld = std::min(minld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
+        if (maxld >= 128 && minld < 128 && !c->blkIn_na && !c->blkOut_na) {   // narrow layers beside wide ones: their own pair (256-B slabs)
+            if ((rc = ensure_blocked(c, true, 16, true))) return rc;
+            if ((rc = ensure_blocked(c, false, 16, true))) return rc;
+        }
         const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
-        const size_t need = (size_t)nbmax * N * (maxld + 64) * sizeof(float);      // + per-(block,row,head) partials
+        size_t need = (size_t)nbmax * N * (maxld + 64) * sizeof(float);            // + per-(block,row,head) partials
+        need = std::max(need, (size_t)std::max(c->blkIn16.nb, c->blkOut16.nb) * N * (std::min<uint32_t>(maxld, 96u) + 64) * sizeof(float));
         if (nbmax && need <= ((size_t)48 << 30) && need > c->partial_bytes) {
             if (c->partial) (void)hipFree(c->partial);
             c->partial = nullptr;

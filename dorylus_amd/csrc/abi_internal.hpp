@@ -102,7 +102,9 @@ bool tf_active(dory_ctx *c);   // = tf_layer(c, 0)
 // one all-to-all-v of rows with the plan of `dir` (abi_comm.hip)
 int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer);
 // K1b bookkeeping (abi_stages.hip)
-int ensure_blocked(dory_ctx *c, bool csc, int group);
+int ensure_blocked(dory_ctx *c, bool csc, int group, bool narrow_set = false /* the multi-head GAT contexts' second pair (ctx.hpp) */);
+// the blocked copy a multi-head GAT layer of leading dimension ld gathers through
+BlockedAdj &gatmh_blocked_for(dory_ctx *c, bool csc, uint32_t ld);
 int blk_group_for(dory_ctx *c, uint32_t ld);
 
 }  // namespace dory

@@ -5,9 +5,14 @@
 namespace dory {
 // ---------------------------------------------------------------------------------------
 // K1b bookkeeping: (re)build the source-blocked copy of one adjacency for `group` lanes/row
-int ensure_blocked(dory_ctx *c, bool csc, int group) {
-    BlockedAdj &B = csc ? c->blkIn : c->blkOut;
-    bool &built = csc ? c->blkIn_built : c->blkOut_built;
+BlockedAdj &gatmh_blocked_for(dory_ctx *c, bool csc, uint32_t ld) {
+    if (ld < 128 && (csc ? c->blkIn16_built : c->blkOut16_built)) return csc ? c->blkIn16 : c->blkOut16;
+    return csc ? c->blkIn : c->blkOut;
+}
+
+int ensure_blocked(dory_ctx *c, bool csc, int group, bool narrow_set) {
+    BlockedAdj &B = narrow_set ? (csc ? c->blkIn16 : c->blkOut16) : (csc ? c->blkIn : c->blkOut);
+    bool &built = narrow_set ? (csc ? c->blkIn16_built : c->blkOut16_built) : (csc ? c->blkIn_built : c->blkOut_built);
     const uint32_t want_nb = (uint32_t)c->opt["spmm_blk_nb"];
     // the block structure serves every slab width; only an explicit block count forces a rebuild
     if (c->capturing && (!built || (want_nb && B.nb != (want_nb + 7) / 8 * 8)) && !(csc ? c->blkIn_na : c->blkOut_na))
@@ -22,10 +27,7 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         // K1b pays nb partial rows per output row: only worth it (and only affordable: the
         // per-(block,row) offset table is nb*(N+1) words) while the source space is a few
         // hundred L2 windows at most.  Larger partitions keep K1.
-        // K1b's own windows (K1s has its own layout: ensure_sweep).  The multi-head GAT sweeps pay more per partial row than
-        // K1b does (statistics beside every partial, three sweeps per layer): 1.5 x the window = 16 blocks instead of 24 at
-        // Reddit size (27.4 -> 26.8-27.0 ms per epoch; 8 blocks: 32.0, 32: 29.2 -- profiles/r04_experiments.txt item 8d)
-        const uint64_t window = c->gnn == DORY_GATMH ? ((uint32_t)group * 16u >= 512u ? (uint64_t)7864320u : (uint64_t)5898240u) : 0;
+        const uint64_t window = 0;   // K1b's own windows (K1s has its own layout: ensure_sweep)
         const uint32_t nb = plan_blocks(NG, want_nb, (uint32_t)group * 16u, window);
         // ... and pointless when the whole source slab fits one XCD's L2 anyway (Cora-sized graphs):
         // K1 then gathers from L2 without partial sums or a second kernel
@@ -33,7 +35,7 @@ int ensure_blocked(dory_ctx *c, bool csc, int group) {
         const bool tiny = !want_nb && (uint64_t)NG * group * 16u <= ((uint64_t)4 << 20) &&
                           !(c->gnn == DORY_GATMH && c->numNodes > 1);
         if (tiny || nb > 256 || (uint64_t)nb * (c->N + 1) * 8ull > ((uint64_t)8 << 30)) {
-            (csc ? c->blkIn_na : c->blkOut_na) = true;
+            if (!narrow_set) (csc ? c->blkIn_na : c->blkOut_na) = true;   // (no second pair: the narrow layers share the first)
             return DORY_OK;
         }
         HIPCK(c, build_blocked(csc ? c->colPtr : c->rowPtr, csc ? c->rowIdx : c->colIdx, csc ? c->cscVal : c->csrVal,
@@ -308,20 +310,21 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         if (dir == DORY_FORWARD) {
             {
                 Timed t(c, "spmm", c->compute);
-                const bool blocked = c->opt["gatmh_blocked"] && c->blkIn_built && !c->blkIn_na && c->blkIn.nb > 0 &&
+                const BlockedAdj &Bf = gatmh_blocked_for(c, true, z->ld);
+                const bool blocked = c->opt["gatmh_blocked"] && c->blkIn_built && !c->blkIn_na && Bf.nb > 0 &&
                                      (D % 4 == 0 || K == 1) &&
-                                     (size_t)c->blkIn.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
+                                     (size_t)Bf.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
                 NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el");
                 if (blocked) {
                     // "gatmh_fused_stats" (default 1): the blocks' own online softmax + a merge in the reduce kernel instead
                     // of a statistics pass over all edges first; the blocks' (m_b, den_b) live in the scratch buffer
                     float *stat_partial = nullptr;
                     if (c->opt["gatmh_fused_stats"]) {
-                        int src_ = ensure_scratch(c, (size_t)2 * c->blkIn.nb * c->N * el->ld * sizeof(float));
+                        int src_ = ensure_scratch(c, (size_t)2 * Bf.nb * c->N * el->ld * sizeof(float));
                         if (src_) return src_;
                         stat_partial = c->scratch;
                     }
-                    HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, c->blkIn, z->d,
+                    HIPCK(c, launch_gatmh_forward_blocked(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, Bf, z->d,
                                                           fgz->d, el->d, fgel->d, er->d, o->d, m->d, den->d, c->partial,
                                                           c->Gsrc > 0, c->compute, stat_partial,
                                                           c->opt["gatmh_el_on_the_fly"] ? c->weights[fl]["a_l"].d : nullptr));
@@ -357,7 +360,8 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         }
         int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
-        const uint32_t nbmax = std::max(c->blkIn.nb, c->blkOut.nb);
+        const BlockedAdj &Bbi = gatmh_blocked_for(c, true, z->ld), &Bbo = gatmh_blocked_for(c, false, z->ld);
+        const uint32_t nbmax = std::max(Bbi.nb, Bbo.nb);
         if (c->opt["gatmh_blocked"] && c->blkIn_built && c->blkOut_built && !c->blkIn_na && !c->blkOut_na && nbmax > 0 &&
             gatmh_backward_blocked_ok(K, D, z->ld) &&
             (size_t)nbmax * c->N * (z->ld + K) * sizeof(float) <= c->partial_bytes) {
@@ -365,7 +369,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             const uint32_t lds4 = st->ld / 4;
             if (phase != 2) {   // destination side: t, der, st
                 Timed t(c, "spmm", c->compute);
-                HIPCK(c, launch_gatmh_backward_blocked_dst(c->N, K, D, z->ld, el->ld, c->blkIn, z->d, fgz->d, el->d, fgel->d,
+                HIPCK(c, launch_gatmh_backward_blocked_dst(c->N, K, D, z->ld, el->ld, Bbi, z->d, fgz->d, el->d, fgel->d,
                                                            er->d, m->d, den->d, dO->d, tt->d, der->d, c->partial, st4, lds4,
                                                            c->Gsrc > 0, c->compute,
                                                            c->opt["gatmh_el_on_the_fly"] ? c->weights[fl]["a_l"].d : nullptr));
@@ -376,7 +380,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 if ((rc = exchange_rows(c, DORY_BACKWARD, st, bgst, false))) return rc;
             }
             Timed t(c, "spmm", c->compute);
-            HIPCK(c, launch_gatmh_backward_blocked_src(c->N, K, D, z->ld, el->ld, c->blkOut, z->d, el->d, dO->d, bgdo->d, st4,
+            HIPCK(c, launch_gatmh_backward_blocked_src(c->N, K, D, z->ld, el->ld, Bbo, z->d, el->d, dO->d, bgdo->d, st4,
                                                        reinterpret_cast<const float4 *>(bgst->d), lds4, der->d,
                                                        c->weights[fl]["a_l"].d, c->weights[fl]["a_r"].d, del->d, dz->d,
                                                        c->partial, c->Gdst > 0, c->compute));

@@ -124,6 +124,10 @@ struct dory_ctx {
     dory::LongRowsDev longIn, longOut;          // K1: hub rows of forwardAdj / backwardAdj
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
+    // multi-head GAT contexts with layers on both sides of 128 floats: a second pair, blocked for the 256-B slabs of the narrow
+    // layers (K1b's windows hold a fixed number of BYTES: 24 blocks of 512-B rows, 16 of 256-B rows at Reddit size)
+    dory::BlockedAdj blkIn16, blkOut16;
+    bool blkIn16_built = false, blkOut16_built = false;
     dory::BlockedAdj swpIn, swpOut;             // K1s layouts (built on first use when spmm_variant == 2)
     bool swpIn_built = false, swpOut_built = false, swpIn_na = false, swpOut_na = false;
     uint32_t swpIn_want_nb = 0, swpOut_want_nb = 0;   // the spmm_blk_nb the layouts were built for
