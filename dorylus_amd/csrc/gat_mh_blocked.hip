@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void gatmh_stats_kernel(GatMhArgs a, const flo
     }
 }
 
-constexpr int GATMH_BLK_ROWS = 64;   // destination rows per workgroup (as K1b)
+#ifndef GATMH_BLK_ROWS_DEF
+#define GATMH_BLK_ROWS_DEF 64
+#endif
+constexpr int GATMH_BLK_ROWS = GATMH_BLK_ROWS_DEF;   // destination rows per workgroup (as K1b)
 
 // sum over the HL neighbouring lanes of a head (first two butterfly steps by DPP inside a quad: see the backward kernels)
 // All inside the VALU: quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E) for the first two butterfly steps, then
