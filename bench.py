@@ -727,7 +727,7 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
             pass
         res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": traffic_, "traffic_source": traffic_src_,
-                           "traffic_what": "HBM-side FETCH bytes per epoch (five launches); algorithmic_bytes_per_epoch is the figure `achieved` uses",
+                           "traffic_what": "HBM-side FETCH bytes per epoch (all its aggregation launches); algorithmic_bytes_per_epoch is the figure `achieved` uses",
                            "kernel": "spmm_rows_kernel<GROUP,CHUNKS> (K1 row gather; %d launches per epoch)" % (2 * nl_ - 1),
                            "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
                            "gathered_bytes_per_epoch": int(gathered), "gathered_TBps": round(gathered / t / 1e12, 3),
