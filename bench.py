@@ -748,6 +748,21 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
                            "kernel": "gatmh_*_blocked_kernel family + reduce kernels (six edge passes per epoch)",
                            "gathered_bytes_per_epoch": int(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) ),
                            "l1_path_frac": round(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) / t / 1e12 / 37.7, 4)}
+    if gnn == "gcn" and dims is not None:
+        # the same partition in the transform-first order (opt-in gcn_transform_first=2, not the reference's schedule): the layers
+        # whose input is wider than their output gather the narrower rows -- on config 4 the 300-float launch becomes a 64-float one
+        ctx.set_option("gcn_transform_first", 2)
+        if ctx.transform_first_active():
+            ctx.timing_enable(False)
+            eng.run(1)
+            ctx.sync()
+            t1 = time.perf_counter()
+            eng.run(steps)
+            ctx.sync()
+            res["transform_first"] = {"ms_per_step": (time.perf_counter() - t1) * 1e3 / steps,
+                                      "what": "opt-in gcn_transform_first=2 on the same partition (z_l = A(in_l W_l) where the layer narrows); "
+                                              "not the reference order, not the figure above"}
+        ctx.set_option("gcn_transform_first", 0)
     eng.close()
     ctx.close()
     return res
