@@ -1,4 +1,6 @@
-// spmm.hip -- K1: CSC/CSR SpMM with fused self term, fp32, for gfx950.
+// spmm.hip -- K1 (row gather, first half of this file) and K1s (the register-accumulating gated sweep, second half: the
+// default where it applies): CSC/CSR SpMM with fused self term, fp32, for gfx950.  K1b, the partial-row form between the
+// two, lives in spmm_blocked.hip; the edge-regrouping kernels both blocked layouts use are spmm_common.hpp.
 //
 // Replaces Engine::aggregateGCN / aggregateGAT (reference
 // src/graph-server/engine/ops/gcn_ops.cpp:130-191, gat_ops.cpp:173-243) and the
@@ -263,7 +265,7 @@ void free_blocked(BlockedAdj *B) {
 
 
 // =======================================================================================
-// K1s: "sweep" -- K1b's blocked adjacency without the partial rows.
+// K1s: "sweep" -- K1b's blocked adjacency (spmm_blocked.hip) without the partial rows.
 //
 // K1b launches one short workgroup per (tile, source block), so a partial row slab is written per block and a second
 // kernel adds them up (27 GB of extra traffic per F=602 launch at Reddit scale, ~5 of 19 ms), and its windows have to be
