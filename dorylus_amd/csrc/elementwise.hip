@@ -122,6 +122,8 @@ static void launch_softmax_rows(uint32_t rows, uint32_t cols, const float *z, ui
     if (cols <= 8) SOFTMAX_LPR(8);
     else if (cols <= 16) SOFTMAX_LPR(16);
     else if (cols <= 32) SOFTMAX_LPR(32);
+    else if (cols <= 48) SOFTMAX_LPR(16);   // e.g. Reddit's 41 classes: three columns per lane, four rows per wave (81 -> 49 us at
+                                            // 232 965 rows against one row per wave with 23 idle lanes and six-step trees)
     else SOFTMAX_LPR(64);
 #undef SOFTMAX_LPR
 }
