@@ -188,6 +188,8 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
     c->opt["gatmh_el_on_the_fly"] = 1;       // multi-head GAT, blocked forward with fused statistics, heads of <= 16 features: el[src] from the gathered row instead of a second gather
+    c->opt["gatmh_sweep"] = 1;               // multi-head GAT: the edge passes on K1s's skeleton (gat_mh_sweep.hip) where the sweep layout and the shape apply (1: forward)
+    c->opt["gatmh_sweep_rows"] = 0;          // rows per lane group of the multi-head GAT contexts' sweep layouts (0 = by fill, at most 8)
     c->opt["gatmh_fused_stats"] = 1;         // multi-head GAT, blocked forward: online softmax per source block + merge in the reduce (0: separate statistics pass first)
     c->opt["gcn_cache_ah0"] = 0;         // GCN: keep ah@0 = A_hat x across epochs while x, fg@0 and the adjacency are unchanged (opt-in; the reference recomputes it)
     c->opt["gcn_transform_first"] = 0;   // GCN layers as A(XW) instead of (AX)W where the input is wider than the output: 1 = layer 0, 2 = all (see tf_layer)
@@ -508,6 +510,24 @@ int dory_preallocate(dory_ctx *c) {
     }
     c->adam.epochs = 1;
     HIPCK(c, hipStreamSynchronize(c->compute));
+    if (c->opt["spmm_variant"] == 2 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_sweep"]) {
+        // the sweep layouts (K1s's even layout; the deal is made for the 32-lane launches) and the gate counters now
+        uint32_t maxld = 0;
+        for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
+        const int group = blk_group_for(c, maxld);
+        if ((rc = ensure_sweep(c, true, group))) return rc;
+        size_t need = 0;
+        if (c->swpIn.nb)
+            for (int g_ : {16, 32})   // (the 16-lane launches of the narrow layers walk fewer rows per group: more sweeps, more counters)
+                need = std::max(need, sweep_scratch_bytes(c->swpIn, g_ == 32 ? maxld : std::min<uint32_t>(maxld, 64u), g_, std::min<uint32_t>(32u, c->cus_per_xcd), c->swpIn.nb, gatmh_sweep_rows(c->swpIn, g_)));
+        if (need > c->partial_bytes) {
+            if (c->partial) (void)hipFree(c->partial);
+            c->partial = nullptr;
+            c->partial_bytes = 0;
+            HIPCK(c, hipMalloc((void **)&c->partial, need));
+            c->partial_bytes = need;
+        }
+    }
     if (c->opt["spmm_variant"] >= 1 && N > 0 && c->gnn == DORY_GATMH && c->opt["gatmh_blocked"]) {
         // the extension's forward sum gathers through the same source-blocked copy of the in-edges
         uint32_t maxld = 0;

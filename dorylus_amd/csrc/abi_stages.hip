@@ -60,7 +60,9 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     if (built || na) return DORY_OK;
     if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: the sweep layout would have to be built while recording");
     const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
-    const int R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);   // the deal is made for the 32-lane launches
+    // the deal is made for the 32-lane launches; the multi-head GAT passes keep more per row in registers: 8 rows at most
+    const int R = c->gnn == DORY_GATMH ? sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["gatmh_sweep_rows"], 8)
+                                       : sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);
     // source window per block.  0 = by the rows a lane group holds: a step costs ~3 us whatever it gathers, and a small
     // partition (one rank of 8: four rows per group) gathers little per step -- fewer, larger windows win there although
     // two of them no longer fit the L2 (measured, one rank of 8 of the Reddit-size graph: 2432 / 3072 / 3584 / 4096 / 5120 KB
@@ -315,7 +317,39 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                                      (D % 4 == 0 || K == 1) &&
                                      (size_t)Bf.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
                 NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el");
-                if (blocked) {
+                const BlockedAdj &Sf = c->swpIn;
+                const bool sweep = c->opt["gatmh_sweep"] && c->opt["spmm_variant"] == 2 && c->swpIn_built && !c->swpIn_na && Sf.nb > 0 &&
+                                   gatmh_sweep_hl(K, D, z->ld) != 0 && Sf.rows_per_group <= 8;
+                if (sweep) {
+                    // K1s's skeleton: sums in registers over all source blocks, single-pass softmax against the upper-bound shift
+                    int src_ = ensure_scratch(c, gatmh_sweep_scratch_bytes(Sf, c->N, z->ld, el->ld));
+                    if (src_) return src_;
+                    const uint32_t G = std::min<uint32_t>(32u, c->cus_per_xcd);
+                    const bool two = c->Gsrc > 0 && Sf.nb_local > 0 && Sf.nb_local < Sf.nb;
+                    const int sgroup = z->ld >= 128 ? 32 : 16;
+                    const size_t need = sweep_scratch_bytes(Sf, z->ld, sgroup, G, two ? std::max(Sf.nb_local, Sf.nb - Sf.nb_local) : Sf.nb, gatmh_sweep_rows(Sf, sgroup));
+                    if (need > c->partial_bytes) return fail(c, DORY_ERR_ARG, "multi-head GAT sweep: gate counters not allocated (preallocate)");
+                    SweepCtl ctl;
+                    ctl.stat = c->sweep_stat;
+                    uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
+                    const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+                    const float *a_l = c->weights[fl]["a_l"].d;
+                    HIPCK(c, launch_gatmh_sweep_begin(c->N, c->Gsrc, K, z->ld, el->ld, Sf, el->d, fgel->d, c->scratch, c->compute));
+                    if (two) {
+                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, c->scratch, G, 0,
+                                                                 Sf.nb_local, false, done, ctl, sflags, c->compute));
+                        if ((src_ = wait_halo(c))) return src_;
+                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, c->scratch, G,
+                                                                 Sf.nb_local, Sf.nb, true, done, ctl, sflags, c->compute));
+                    } else {
+                        if ((src_ = wait_halo(c))) return src_;
+                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, c->Gsrc ? fgz->d : nullptr, er->d, a_l, o->d,
+                                                                 c->scratch, G, 0, Sf.nb, false, done, ctl, sflags, c->compute));
+                    }
+                    HIPCK(c, launch_gatmh_forward_sweep_finish(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, Sf, z->d, fgz->d, el->d, fgel->d,
+                                                               er->d, o->d, m->d, den->d, c->scratch, c->compute));
+                }
+                else if (blocked) {
                     // "gatmh_fused_stats" (default 1): the blocks' own online softmax + a merge in the reduce kernel instead
                     // of a statistics pass over all edges first; the blocks' (m_b, den_b) live in the scratch buffer
                     float *stat_partial = nullptr;
