@@ -451,6 +451,8 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "dz", N, zw);
             for (const char *nm : {"el", "er", "m", "den", "t", "del", "der"}) mk(l, nm, N, K);
             mk(l, "st", N, 4 * K);               // (er, m, 1/den, t) per (v,k): what the source-side sweep gathers per edge
+            mk(l, "op", N, zw);                  // the part of "o" that came over edges on LeakyReLU's positive branch (sweep forward)
+            mk(l, "dpos", N, K);                 // and the attention mass of those edges
             // partitioned runs: ghost sources of the in-edges (z exchanged forward, el/er recomputed from it) and
             // ghost destinations of the out-edges (dO and st exchanged between the two phases of the backward sweep)
             mk(l, "fg_z", c->Gsrc, zw);
@@ -516,10 +518,13 @@ int dory_preallocate(dory_ctx *c) {
         for (uint32_t l = 0; l < L; ++l) maxld = std::max(maxld, pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]));
         const int group = blk_group_for(c, maxld);
         if ((rc = ensure_sweep(c, true, group))) return rc;
+        if ((rc = ensure_sweep(c, false, group))) return rc;
+        c->gatmh_fwd_swept.assign(L, 0);
         size_t need = 0;
-        if (c->swpIn.nb)
-            for (int g_ : {16, 32})   // (the 16-lane launches of the narrow layers walk fewer rows per group: more sweeps, more counters)
-                need = std::max(need, sweep_scratch_bytes(c->swpIn, g_ == 32 ? maxld : std::min<uint32_t>(maxld, 64u), g_, std::min<uint32_t>(32u, c->cus_per_xcd), c->swpIn.nb, gatmh_sweep_rows(c->swpIn, g_)));
+        for (const BlockedAdj *S : {&c->swpIn, &c->swpOut})
+            if (S->nb)
+                for (int g_ : {16, 32})   // (launches walk fewer rows per group than the layout deals: more sweeps, more counters; 2 is the least)
+                    need = std::max(need, sweep_scratch_bytes(*S, g_ == 32 ? maxld : std::min<uint32_t>(maxld, 64u), g_, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb, 2));
         if (need > c->partial_bytes) {
             if (c->partial) (void)hipFree(c->partial);
             c->partial = nullptr;

@@ -60,14 +60,25 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     if (built || na) return DORY_OK;
     if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: the sweep layout would have to be built while recording");
     const uint32_t NG = c->N + (csc ? c->Gsrc : c->Gdst);
-    // the deal is made for the 32-lane launches; the multi-head GAT passes keep more per row in registers: 8 rows at most
-    const int R = c->gnn == DORY_GATMH ? sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["gatmh_sweep_rows"], 8)
-                                       : sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);
+    // the deal is made for the 32-lane launches; the multi-head GAT passes keep ten registers per row: 4 rows at most
+    int R;
+    if (c->gnn == DORY_GATMH) {
+        // four rows while that fills every CU at least once (fewer sweeps = fewer refills of every window: 4.47 -> 4.17 ms per
+        // 128-float forward launch from two rows to four); small partitions pick by fill
+        const uint32_t G_ = std::min<uint32_t>(32u, c->cus_per_xcd);
+        const int forced = (int)c->opt["gatmh_sweep_rows"];
+        R = (!forced && c->N >= 8u * G_ * 32u * 4u) ? 4 : sweep_pick_r(c->N, 32, G_, forced, 4);
+    } else {
+        R = sweep_pick_r(c->N, 32, std::min<uint32_t>(32u, c->cus_per_xcd), (int)c->opt["spmm_sweep_rows"]);
+    }
     // source window per block.  0 = by the rows a lane group holds: a step costs ~3 us whatever it gathers, and a small
     // partition (one rank of 8: four rows per group) gathers little per step -- fewer, larger windows win there although
     // two of them no longer fit the L2 (measured, one rank of 8 of the Reddit-size graph: 2432 / 3072 / 3584 / 4096 / 5120 KB
     // = 3.34 / 3.22 / 3.16 / 3.21 / 3.38 ms per epoch; ranks of 4, 2 and the whole graph: 2432 KB stays best)
-    const uint64_t window_kb = c->opt["spmm_sweep_window_kb"] ? (uint64_t)c->opt["spmm_sweep_window_kb"] : (R <= 4 ? 3584u : 2432u);
+    // (multi-head GAT contexts: their sweeps carry 13-17 vector instructions per gather and two to four rows per group, and run
+    // best on 4.5 MB windows -- 128-float forward 4.45 / 4.16 / 4.09 / 4.29 / 4.88 ms at 2432 / 3584 / 4608 / 6144 / 8192 KB)
+    const uint64_t window_kb = c->opt["spmm_sweep_window_kb"] ? (uint64_t)c->opt["spmm_sweep_window_kb"]
+                                                              : (c->gnn == DORY_GATMH && R >= 4 ? 4608u : (R <= 4 ? 3584u : 2432u));
     const uint64_t window = window_kb << 10;
     const uint64_t nb_est = ((uint64_t)NG * group * 16u + window - 1) / window + 1;
     // the whole source slab in one L2 (Cora-sized graphs): K1 gathers from L2 anyway.  Thousands of windows (Amazon-,
@@ -318,8 +329,11 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                                      (size_t)Bf.nb * c->N * z->ld * sizeof(float) <= c->partial_bytes;
                 NEED(fgz, fl, "fg_z"); NEED(fgel, fl, "fg_el");
                 const BlockedAdj &Sf = c->swpIn;
+                const int shl = gatmh_sweep_hl(K, D, z->ld);
+                Tensor *op = find(c, fl, "op"), *dpos = find(c, fl, "dpos");
                 const bool sweep = c->opt["gatmh_sweep"] && c->opt["spmm_variant"] == 2 && c->swpIn_built && !c->swpIn_na && Sf.nb > 0 &&
-                                   gatmh_sweep_hl(K, D, z->ld) != 0 && Sf.rows_per_group <= 8;
+                                   shl != 0 && op && dpos;
+                if (fl < c->gatmh_fwd_swept.size()) c->gatmh_fwd_swept[fl] = 0;
                 if (sweep) {
                     // K1s's skeleton: sums in registers over all source blocks, single-pass softmax against the upper-bound shift
                     int src_ = ensure_scratch(c, gatmh_sweep_scratch_bytes(Sf, c->N, z->ld, el->ld));
@@ -327,7 +341,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                     const uint32_t G = std::min<uint32_t>(32u, c->cus_per_xcd);
                     const bool two = c->Gsrc > 0 && Sf.nb_local > 0 && Sf.nb_local < Sf.nb;
                     const int sgroup = z->ld >= 128 ? 32 : 16;
-                    const size_t need = sweep_scratch_bytes(Sf, z->ld, sgroup, G, two ? std::max(Sf.nb_local, Sf.nb - Sf.nb_local) : Sf.nb, gatmh_sweep_rows(Sf, sgroup));
+                    const size_t need = sweep_scratch_bytes(Sf, z->ld, sgroup, G, two ? std::max(Sf.nb_local, Sf.nb - Sf.nb_local) : Sf.nb, gatmh_sweep_rows(Sf, sgroup, shl, 0));
                     if (need > c->partial_bytes) return fail(c, DORY_ERR_ARG, "multi-head GAT sweep: gate counters not allocated (preallocate)");
                     SweepCtl ctl;
                     ctl.stat = c->sweep_stat;
@@ -336,18 +350,19 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                     const float *a_l = c->weights[fl]["a_l"].d;
                     HIPCK(c, launch_gatmh_sweep_begin(c->N, c->Gsrc, K, z->ld, el->ld, Sf, el->d, fgel->d, c->scratch, c->compute));
                     if (two) {
-                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, c->scratch, G, 0,
+                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, op->d, c->scratch, G, 0,
                                                                  Sf.nb_local, false, done, ctl, sflags, c->compute));
                         if ((src_ = wait_halo(c))) return src_;
-                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, c->scratch, G,
+                        HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, op->d, c->scratch, G,
                                                                  Sf.nb_local, Sf.nb, true, done, ctl, sflags, c->compute));
                     } else {
                         if ((src_ = wait_halo(c))) return src_;
                         HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, c->Gsrc ? fgz->d : nullptr, er->d, a_l, o->d,
-                                                                 c->scratch, G, 0, Sf.nb, false, done, ctl, sflags, c->compute));
+                                                                 op->d, c->scratch, G, 0, Sf.nb, false, done, ctl, sflags, c->compute));
                     }
                     HIPCK(c, launch_gatmh_forward_sweep_finish(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, Sf, z->d, fgz->d, el->d, fgel->d,
-                                                               er->d, o->d, m->d, den->d, c->scratch, c->compute));
+                                                               er->d, o->d, op->d, m->d, den->d, dpos->d, c->scratch, c->compute));
+                    if (fl < c->gatmh_fwd_swept.size()) c->gatmh_fwd_swept[fl] = 1;
                 }
                 else if (blocked) {
                     // "gatmh_fused_stats" (default 1): the blocks' own online softmax + a merge in the reduce kernel instead
@@ -394,6 +409,61 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         }
         int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
+        // The sweep forms (gat_mh_sweep.hip).  Destination side: when this layer's forward ran on the skeleton it left the
+        // positive-branch sums, and t / der / st come from a row-wise kernel -- no edge pass.  Source side: the sweep over the
+        // out-edges' layout.  Either falls back to the blocked kernels on its own (same m / den / st semantics).
+        const int shl = gatmh_sweep_hl(K, D, z->ld);
+        Tensor *op = find(c, fl, "op"), *dpos = find(c, fl, "dpos");
+        const bool dst_rowwise = c->opt["gatmh_sweep"] && shl && op && dpos && fl < c->gatmh_fwd_swept.size() && c->gatmh_fwd_swept[fl] &&
+                                 ((z->ld >> 2) % (uint32_t)shl) == 0;
+        const BlockedAdj &So = c->swpOut;
+        const bool src_sweep = c->opt["gatmh_sweep"] && c->opt["spmm_variant"] == 2 && shl && c->swpOut_built && !c->swpOut_na && So.nb > 0 &&
+                               ((z->ld >> 2) % (uint32_t)shl) == 0;
+        if (dst_rowwise && src_sweep) {
+            float4 *st4 = reinterpret_cast<float4 *>(st->d);
+            const uint32_t lds4 = st->ld / 4;
+            if (phase != 2) {
+                Timed t(c, "loss", c->compute);
+                HIPCK(c, launch_gatmh_dst_rowwise(c->N, K, D, z->ld, el->ld, dO->d, o->d, op->d, dpos->d, er->d, m->d, den->d, tt->d, der->d,
+                                                  st4, lds4, c->compute));
+            }
+            if (phase == 1) return DORY_OK;
+            if (phase == 0 && c->numNodes > 1) {   // ghost destinations of the out-edges: their dO and st rows
+                if ((rc = exchange_rows(c, DORY_BACKWARD, dO, bgdo, false))) return rc;
+                if ((rc = exchange_rows(c, DORY_BACKWARD, st, bgst, false))) return rc;
+            }
+            if ((rc = ensure_scratch(c, gatmh_src_sweep_scratch_bytes(So, c->N, c->Gdst, K, z->ld, el->ld)))) return rc;
+            const uint32_t G = std::min<uint32_t>(32u, c->cus_per_xcd);
+            const bool two = c->Gdst > 0 && So.nb_local > 0 && So.nb_local < So.nb;
+            const int sgroup = z->ld >= 128 ? 32 : 16;
+            const size_t need = sweep_scratch_bytes(So, z->ld, sgroup, G, two ? std::max(So.nb_local, So.nb - So.nb_local) : So.nb, gatmh_sweep_rows(So, sgroup, shl, 1));
+            if (need > c->partial_bytes) return fail(c, DORY_ERR_ARG, "multi-head GAT sweep: gate counters not allocated (preallocate)");
+            SweepCtl ctl;
+            ctl.stat = c->sweep_stat;
+            uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
+            const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+            {
+                Timed t(c, "spmm", c->compute);
+                HIPCK(c, launch_gatmh_src_sweep_begin(c->N, c->Gdst, K, z->ld, el->ld, So, st4, reinterpret_cast<const float4 *>(bgst->d), lds4,
+                                                      c->scratch, c->compute));
+                if (two) {
+                    HIPCK(c, launch_gatmh_src_sweep_part(c->N, c->Gdst, K, D, z->ld, el->ld, So, dO->d, bgdo->d, el->d, dz->d, c->scratch, G, 0,
+                                                         So.nb_local, false, done, ctl, sflags, c->compute));
+                    HIPCK(c, launch_gatmh_src_sweep_part(c->N, c->Gdst, K, D, z->ld, el->ld, So, dO->d, bgdo->d, el->d, dz->d, c->scratch, G,
+                                                         So.nb_local, So.nb, true, done, ctl, sflags, c->compute));
+                } else {
+                    HIPCK(c, launch_gatmh_src_sweep_part(c->N, c->Gdst, K, D, z->ld, el->ld, So, dO->d, c->Gdst ? bgdo->d : nullptr, el->d, dz->d,
+                                                         c->scratch, G, 0, So.nb, false, done, ctl, sflags, c->compute));
+                }
+                HIPCK(c, launch_gatmh_src_sweep_finish(c->N, K, D, z->ld, el->ld, So, z->d, el->d, dO->d, der->d, c->weights[fl]["a_l"].d,
+                                                       c->weights[fl]["a_r"].d, del->d, dz->d, c->scratch, c->compute));
+            }
+            // (the attention gradients' column sums take the scratch buffer next: the sweep's sums are consumed by then)
+            if ((rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + 256))) return rc;
+            HIPCK(c, launch_gatmh_dattn(c->N, K, D, z->ld, el->ld, z->d, del->d, der->d, c->wgrads[fl]["a_l"].d,
+                                        c->wgrads[fl]["a_r"].d, c->scratch, c->scratch_bytes, c->compute));
+            return DORY_OK;
+        }
         const BlockedAdj &Bbi = gatmh_blocked_for(c, true, z->ld), &Bbo = gatmh_blocked_for(c, false, z->ld);
         const uint32_t nbmax = std::max(Bbi.nb, Bbo.nb);
         if (c->opt["gatmh_blocked"] && c->blkIn_built && c->blkOut_built && !c->blkIn_na && !c->blkOut_na && nbmax > 0 &&

@@ -140,6 +140,7 @@ struct dory_ctx {
                                                 // it), workgroups of the launch in flight that have left
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
+    std::vector<char> gatmh_fwd_swept;   // multi-head GAT: the forward of this layer ran on the sweep skeleton ("op", "dpos" are current)
     float *partial = nullptr;
     size_t partial_bytes = 0;
 
@@ -344,20 +345,33 @@ hipError_t launch_gatmh_backward_blocked_src(uint32_t N, uint32_t K, uint32_t D,
                                              const float *der, const float *a_l, const float *a_r, float *del, float *dz,
                                              float *partial /*nb x N x (ld + K) floats*/, bool ghosts, hipStream_t s);
 // the edge passes on K1s's skeleton (csrc/gat_mh_sweep.hip): register-resident sums over all source blocks of the sweep layout,
-// single-pass softmax against a per-(v,k) upper-bound shift
+// single-pass softmax against a per-(v,k) upper-bound shift; the destination side of the backward pass needs no edges
 int gatmh_sweep_hl(uint32_t K, uint32_t D, uint32_t ld);   // lanes per head; 0 = shape not covered (blocked kernels)
-int gatmh_sweep_rows(const BlockedAdj &S, int group);      // rows per lane group of a launch on `group`-lane slabs
+int gatmh_sweep_rows(const BlockedAdj &S, int group, int HL, int pass /*0 forward, 1 source side*/);   // rows per lane group of a launch
 size_t gatmh_sweep_scratch_bytes(const BlockedAdj &S, uint32_t N, uint32_t ld, uint32_t ldk);
 hipError_t launch_gatmh_sweep_begin(uint32_t N, uint32_t G, uint32_t K, uint32_t ld, uint32_t ldk, const BlockedAdj &S, const float *el,
                                     const float *elg, float *scratch, hipStream_t s);
 hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const BlockedAdj &S,
-                                           const float *z, const float *zg, const float *er, const float *a_l, float *o, float *scratch,
-                                           uint32_t cus, uint32_t b_lo, uint32_t b_hi, bool accumulate, uint32_t *done, const SweepCtl &ctl,
-                                           uint32_t flags, hipStream_t s);
+                                           const float *z, const float *zg, const float *er, const float *a_l, float *o, float *op,
+                                           float *scratch, uint32_t cus, uint32_t b_lo, uint32_t b_hi, bool accumulate, uint32_t *done,
+                                           const SweepCtl &ctl, uint32_t flags, hipStream_t s);
 hipError_t launch_gatmh_forward_sweep_finish(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                              const uint32_t *rowidx, const BlockedAdj &S, const float *z, const float *zg, const float *el,
-                                             const float *elg, const float *er, float *o, float *m, float *den, float *scratch,
-                                             hipStream_t s);
+                                             const float *elg, const float *er, float *o, float *op, float *m, float *den, float *dpos,
+                                             float *scratch, hipStream_t s);
+hipError_t launch_gatmh_dst_rowwise(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const float *d_o, const float *o,
+                                    const float *op, const float *dpos, const float *er, const float *m, const float *den, float *t,
+                                    float *der, float4 *st4, uint32_t lds4, hipStream_t s);
+size_t gatmh_src_sweep_scratch_bytes(const BlockedAdj &S, uint32_t N, uint32_t G, uint32_t K, uint32_t ld, uint32_t ldk);
+hipError_t launch_gatmh_src_sweep_begin(uint32_t N, uint32_t G, uint32_t K, uint32_t ld, uint32_t ldk, const BlockedAdj &S,
+                                        const float4 *st4, const float4 *stg, uint32_t lds4, float *scratch, hipStream_t s);
+hipError_t launch_gatmh_src_sweep_part(uint32_t N, uint32_t G, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const BlockedAdj &S,
+                                       const float *d_o, const float *dog, const float *el, float *dz, float *scratch, uint32_t cus,
+                                       uint32_t b_lo, uint32_t b_hi, bool accumulate, uint32_t *done, const SweepCtl &ctl, uint32_t flags,
+                                       hipStream_t s);
+hipError_t launch_gatmh_src_sweep_finish(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const BlockedAdj &S, const float *z,
+                                         const float *el, const float *d_o, const float *der, const float *a_l, const float *a_r, float *del,
+                                         float *dz, float *scratch, hipStream_t s);
 // row-wise backward (single partition; feature-per-lane or (edge, head, piece)-per-lane kernels by shape)
 hipError_t launch_gatmh_backward(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                  const uint32_t *rowidx, const uint64_t *rowptr, const uint32_t *colidx,

@@ -300,14 +300,17 @@ void free_blocked(BlockedAdj *B) {
 // The skeleton (gates, loader wave, staging, batches of gathers) is sweep_core.hpp; the plain SpMM is this OP on it.
 template <bool UNIT>
 struct SweepPlainOp {
-    static constexpr bool PLAIN = true, UNIT_W = UNIT, PROLOGUE = false;
-    static constexpr int PIPE = 0;            // the classic walk (addresser-bound: batches ahead buy nothing, measured in round 2)
+    static constexpr bool PLAIN = true, UNIT_W = UNIT, PROLOGUE = false, AUX_BATCH = false;
+    static constexpr int BATCH = SWEEP_U;     // gathers per batch
     const float *row_scale;
     struct Row { float4 acc; };
     struct RowC {};
+    typedef uint32_t Aux;                       // the entry's weight (bits)
+    __device__ __forceinline__ Aux aux(uint32_t, uint32_t vbits, bool) const { return vbits; }
+    template <int NB> __device__ __forceinline__ void aux_batch(const uint2 *, uint32_t, Aux (&)[NB]) const {}
     __device__ __forceinline__ void init(Row &r) const { r.acc = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ RowC row_const(uint32_t) const { return RowC{}; }
-    __device__ __forceinline__ void prologue(const SpmmArgs &, const BlockedAdj &, uint32_t, uint32_t, uint32_t, uint32_t, int) {}
+    __device__ __forceinline__ void prologue(const SpmmArgs &, const BlockedAdj &, uint32_t, uint32_t, bool, uint32_t, int) {}
     template <bool FULL>
     __device__ __forceinline__ void entry(Row &r, const RowC &, const float4 &x, uint32_t vbits, bool on) const {
         const float wv = UNIT ? 1.f : __uint_as_float(vbits);
@@ -594,7 +597,10 @@ bool sweep_supported(const SpmmArgs &a, const BlockedAdj &B, int group) {
 static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G, int force_r) {
     const int forced = sweep_pick_r(0, group, G, force_r, 10);      // (returns the forced value whatever N when one is valid)
     if (force_r && forced == force_r) return forced;
-    if (B.rows_per_group && (group == 32 || B.rows_per_group <= 8)) return (int)B.rows_per_group;
+    // (16-lane groups stage twice the entries per lane: eight rows spill two registers into the chain LDS -> gathers -> sums;
+    // a spilling variant is not launched unless an option forces it -- tests/test_kernel_resources.py)
+    if (B.rows_per_group && group == 16) return std::min<int>((int)B.rows_per_group, 6);
+    if (B.rows_per_group && group == 32) return (int)B.rows_per_group;
     return sweep_pick_r(B.npos, group, G, 0, 10);
 }
 

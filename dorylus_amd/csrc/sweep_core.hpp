@@ -124,7 +124,7 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
     constexpr int NGRP = SWEEP_NT / GROUP;
     constexpr int NW = SWEEP_NT / 64;
     constexpr int RW = NGRP * R;
-    constexpr int C = SWEEP_C, U = SWEEP_U, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
+    constexpr int C = SWEEP_C, U = OP::BATCH, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
     constexpr int NBUF = LOADER ? 3 : 1;
     constexpr int OFFB = (RW + 1 + 63) / 64 * 64;           // LOADER: the block's base (lo, hi) sits behind the copied offsets
     static_assert(!LOADER || (GROUP == 32 && C == 128), "the loader copies one 1 KB slot per lane group and instruction");
@@ -221,7 +221,7 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
     };
 
     if constexpr (OP::PROLOGUE) {    // the OP's tables of this workgroup's rows (LDS)
-        op.prologue(a, B, xcd * w.rpx + t * (uint32_t)RW, xend, (uint32_t)RW, col, li);
+        op.prologue(a, B, xcd * w.rpx + t * (uint32_t)RW, xend, w.b_lo >= B.nb_local, col, li);
         __syncthreads();
     }
     uint32_t my_o = 0;
@@ -362,55 +362,6 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
                     }
                 }
             }
-            } else if constexpr (OP::PIPE > 0) {
-            // An OP with real work per entry (the multi-head GAT passes: ~16 vector instructions per gather against the
-            // plain sum's 2) is bound by the SUM of the addresser's and the VALU's time in the walk below -- a wave waits
-            // for its batch, then computes with nothing in flight (measured, round 5: 3.78 ms per 128-float forward launch
-            // whatever the rows per group, gates on or off: 34 cycles per gather instruction and CU for 16 of each).  Here
-            // every batch (PIPE entries, predicated by its count) is requested before the batch in front of it is
-            // consumed, across row boundaries: the gathers of row r + 1 are in flight under the arithmetic of row r.
-            constexpr int PU = OP::PIPE;
-            float4 px[PU];
-            uint32_t pw[PU];
-            uint32_t pe = max(ol[0], cs), pn;
-            {
-                const uint32_t hi0 = min(ol[1], ce);
-                pn = hi0 > pe ? min(hi0 - pe, (uint32_t)PU) : 0u;
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    const uint2 en = st[pe + u - cs];
-                    px[u] = gather(en.x, (uint32_t)u < pn);
-                    pw[u] = en.y;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t hi = min(ol[r + 1], ce);
-                const uint32_t lo1 = r + 1 < R ? max(ol[r + 1], cs) : 0u, hi1 = r + 1 < R ? min(ol[r + 2], ce) : 0u;
-                const typename OP::RowC rc = op.row_const((uint32_t)(g * R + r));
-                while (true) {
-                    const uint32_t e_next = pe + pn;
-                    const bool more = e_next < hi;
-                    const uint32_t ne = more ? e_next : (r + 1 < R ? lo1 : e_next);
-                    const uint32_t nn = more ? min(hi - e_next, (uint32_t)PU) : (r + 1 < R && hi1 > lo1 ? min(hi1 - lo1, (uint32_t)PU) : 0u);
-                    float4 nx[PU];
-                    uint32_t nw[PU];
-                    if (more || r + 1 < R) {
-#pragma unroll
-                        for (int u = 0; u < PU; ++u) {
-                            const uint2 en = st[ne + u - cs];
-                            nx[u] = gather(en.x, (uint32_t)u < nn);
-                            nw[u] = en.y;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) op.template entry<false>(rows[r], rc, px[u], pw[u], (uint32_t)u < pn);
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) { px[u] = nx[u]; pw[u] = nw[u]; }
-                    pn = nn; pe = ne;
-                    if (!more) break;
-                }
-            }
             } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -427,23 +378,35 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
                     for (int u = 0; u < U; ++u) en[u] = st[e + u - cs];
                     for (; e + U <= hi; e += U) {               // full batches: nothing predicated
                         float4 x[U];
-                        uint32_t wv[U];
+                        typename OP::Aux ax[U];                  // the entry's weight bits, or the OP's second gather
 #pragma unroll
-                        for (int u = 0; u < U; ++u) { x[u] = gather(en[u].x, true); wv[u] = en[u].y; }
+                        for (int u = 0; u < U; ++u) x[u] = gather(en[u].x, true);
+                        if constexpr (OP::AUX_BATCH) {           // one second-table gather for the whole batch
+                            op.template aux_batch<U>(&st[e - cs], (uint32_t)U, ax);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) ax[u] = op.aux(en[u].x, en[u].y, true);
+                        }
 #pragma unroll
                         for (int u = 0; u < U; ++u) en[u] = st[e + U + u - cs];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) op.template entry<true>(rows[r], rc, x[u], wv[u], true);
+                        for (int u = 0; u < U; ++u) op.template entry<true>(rows[r], rc, x[u], ax[u], true);
                     }
                     if (e < hi) {                                // tail: 1 .. U-1 edges
                         const uint32_t n = hi - e;
                         float4 x[U - 1];
+                        typename OP::Aux ax[U - 1];
+#pragma unroll
+                        for (int u = 0; u < U - 1; ++u) x[u] = gather(en[u].x, (uint32_t)u < n);
+                        if constexpr (OP::AUX_BATCH) {
+                            op.template aux_batch<U - 1>(&st[e - cs], n, ax);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U - 1; ++u) ax[u] = op.aux(en[u].x, en[u].y, (uint32_t)u < n);
+                        }
 #pragma unroll
                         for (int u = 0; u < U - 1; ++u)
-                            x[u] = gather(en[u].x, (uint32_t)u < n);
-#pragma unroll
-                        for (int u = 0; u < U - 1; ++u)
-                            op.template entry<false>(rows[r], rc, x[u], en[u].y, (uint32_t)u < n);
+                            op.template entry<false>(rows[r], rc, x[u], ax[u], (uint32_t)u < n);
                     }
                 }
             }

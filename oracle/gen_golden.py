@@ -144,7 +144,7 @@ def gen_numpy_gnn_fixture():
     print("numpy-gnn fixture written")
 
 
-def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
+def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96, hub=False):
     """The reference's numpy GCN at ~2 000 vertices with the layer widths of a BASELINE config (any depth).  Kept small:
     inputs are regenerated from the stored seed-free arrays (edges, X, labels, W), expected outputs are float32 rows of
     a fixed sample of vertices for every intermediate tensor plus the complete weight gradients."""
@@ -153,7 +153,7 @@ def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
     import load_data as ref_load
     import loss as ref_loss
     L = len(dims) - 1
-    src, dst = toy_edges(seed, V, E, symmetric=True, dedup=True)
+    src, dst = toy_edges(seed, V, E, hub=hub, symmetric=True, dedup=True)   # hub: vertices 3 and 5 neighbour most of the graph
     rng = np.random.default_rng(seed + 1)
     Xq = rng.integers(-64, 65, (V, dims[0])).astype(np.int8)      # features in 1/64 steps: one byte each in the fixture
     X = Xq.astype(np.float32) / np.float32(64)
@@ -190,6 +190,8 @@ def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96):
         grad = lins[l - 1].backward(out[f"g{l-1}"])
         out[f"dW{l-1}"] = lins[l - 1].grad_W
     sample = np.sort(np.random.default_rng(seed + 2).choice(V, rows, replace=False))
+    if hub:
+        sample = np.unique(np.concatenate([sample, [3, 5]]))          # the hub rows are always among the compared rows
     store = {"V": V, "src": src, "dst": dst, "X_q64": Xq, "labels": labels, "sample": sample, "dims": np.asarray(dims)}
     for l in range(L):
         store[f"W{l}"] = Ws[l]
@@ -221,3 +223,5 @@ if __name__ == "__main__":
     gen_numpy_gnn_fixture()
     gen_numpy_gnn_large("numpy_gnn_reddit_dims", [602, 128, 41])            # BASELINE config 2 widths
     gen_numpy_gnn_large("numpy_gnn_amazon_dims", [300, 64, 64, 25], seed=29)  # config 4: 3 layers
+    # round 5: 4 096 vertices (the dense A_hat of the Python model still fits) with two hub rows of ~3 500 neighbours
+    gen_numpy_gnn_large("numpy_gnn_hub4k", [602, 128, 41], V=4096, E=40000, seed=31, rows=128, hub=True)

@@ -192,3 +192,61 @@ def oracle_gat_epoch(g, H0, labels, Ws, As):
         if l > 0:
             grad = orc.sgemm(aTg, Ws[l], tb=True)
     return T, dWs, das
+
+
+def oracle_gat_epoch_parts(gs, parts, H0, labels, Ws, As):
+    """One synchronous epoch of the reference's GAT prototype over P in-process partitions with the C oracle: stage order
+    of SURVEY.md 3.3 (AV -> SC -> AE -> GA per layer, predict, then SC -> AE -> GA -> AV per layer backwards); the ghost
+    exchange is the semantic oracle of SURVEY.md 8c for Engine::scatterGAT / ghostReceiverGAT (gat_ops.cpp:277-435):
+    fg_z[slot(gvid)] = owner.z[lvid(gvid)] forward, bg_d[slot(gvid)] = owner.grad[lvid(gvid)] backward.
+    H0, labels: global (V rows).  Returns per-partition tensor dicts, dW and da summed over the partitions."""
+    P, L = len(gs), len(Ws)
+    g2l = {}
+    for r, g in enumerate(gs):
+        for l, gv in enumerate(g["localToGlobal"]):
+            g2l[int(gv)] = (r, l)
+
+    def ghosts(key, tensors):
+        out = []
+        for g in gs:
+            F = tensors[0].shape[1]
+            rows = [tensors[g2l[int(gv)][0]][g2l[int(gv)][1]] for gv in g[key]]
+            out.append(np.asarray(rows, np.float32).reshape(len(rows), F))
+        return out
+
+    T = [dict() for _ in range(P)]
+    feats = [H0[g["localToGlobal"]] for g in gs]
+    for l in range(L):
+        zs = [orc.sgemm(feats[r], Ws[l]) for r in range(P)]                                          # AV fwd
+        fgz = ghosts("srcGhost", zs)                                                                 # SC fwd
+        nf = []
+        for r, g in enumerate(gs):
+            az, A = orc.edge_forward_gat(g["colPtr"], zs[r], As[l])                                  # AE fwd
+            ah = orc.aggregate_gat_fwd(g["colPtr"], g["rowIdx"], A, zs[r], fgz[r])                   # GA fwd
+            T[r].update({f"in{l}": feats[r], f"z{l}": zs[r], f"fg_z{l}": fgz[r], f"az{l}": az, f"A{l}": A, f"ah{l}": ah})
+            nf.append(ah)
+        feats = nf
+    C = Ws[-1].shape[1]
+    grads = []
+    for r, g in enumerate(gs):
+        lab = np.eye(C, dtype=np.float32)[labels[g["localToGlobal"]]]
+        pr = np.empty_like(feats[r])
+        if feats[r].shape[0]:
+            orc.lib.orc_softmax(feats[r].shape[0], C, np.ascontiguousarray(feats[r]), pr)            # predictGAT
+        grads.append((pr - lab).astype(np.float32))
+    dWs, das = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        bgd = ghosts("dstGhost", grads)                                                              # SC bwd
+        ngr = []
+        for r, g in enumerate(gs):
+            T[r][f"grad{l}"], T[r][f"bg_d{l}"] = grads[r], bgd[r]
+            dA, da = orc.edge_backward_gat(g["colPtr"], grads[r], T[r][f"az{l}"], T[r][f"z{l}"], As[l])   # AE bwd
+            aTg = orc.aggregate_gat_bwd(g["rowPtr"], g["colIdx"], g["csrVal"], grads[r], bgd[r],
+                                        g["colPtr"], g["rowIdx"], dA, T[r][f"z{l}"], T[r][f"fg_z{l}"])    # GA bwd
+            T[r][f"dA{l}"], T[r][f"aTg{l}"] = dA, aTg
+            dw = orc.sgemm(T[r][f"in{l}"], aTg, ta=True)                                             # AV bwd
+            dWs[l] = dw if dWs[l] is None else dWs[l] + dw
+            das[l] = da if das[l] is None else das[l] + da
+            ngr.append(orc.sgemm(aTg, Ws[l], tb=True) if l > 0 else None)
+        grads = ngr
+    return T, dWs, das

@@ -142,6 +142,7 @@ def test_gat_mh_partitioned_epoch_vs_oracle(P, dims, heads):
         _, _, ld, _ = ctxs[0].info(layer, src_name)
         send = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][0])) * ld, device="cuda") for r in range(P)]
         recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][1])) * ld, device="cuda") for r in range(P)]
+        torch.cuda.synchronize()   # (the contexts' streams are non-blocking: torch's zero fills must have landed before a pack kernel writes)
         for r in range(P):
             ctxs[r].halo_pack_tensor(layer, src_name, dd, send[r].data_ptr())
             ctxs[r].sync()

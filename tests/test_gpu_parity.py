@@ -362,6 +362,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
         _, _, ld, _ = ctxs[0].info(src_layer, src_name)
         send = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][0])) * ld, device="cuda") for r in range(P)]
         recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][d][1])) * ld, device="cuda") for r in range(P)]
+        torch.cuda.synchronize()   # (the contexts' streams are non-blocking: torch's zero fills must have landed before a pack kernel writes)
         for r in range(P):
             ctxs[r].halo_pack(layer, d, send[r].data_ptr())
             ctxs[r].sync()
@@ -417,7 +418,7 @@ def _run_gcn_epochs(da, gs, parts, dims, X, labels, Ws, epochs=1, lr=0.01, nativ
 @pytest.mark.parametrize("blk_nb", [0, 8])   # 8: the source-blocked K1b kernels even on these L2-sized graphs
 def test_gcn_epoch_vs_oracle(da, case, dims, blk_nb):
     """Whole forward+backward epoch, every named tensor, P partitions with halo."""
-    from helpers import oracle_gcn_epoch, rel_err
+    from helpers import assert_parity, oracle_gcn_epoch, rel_err
     gs, parts = _golden_partitions(case)
     V = int(gs[0]["globalVtxCnt"])
     rng = np.random.default_rng(7)
@@ -432,21 +433,21 @@ def test_gcn_epoch_vs_oracle(da, case, dims, blk_nb):
         if gs[r]["localVtxCnt"] == 0:
             continue
         for l in range(L):
-            assert rel_err(c.download(l, "ah"), T[r][f"ah{l}"]) < RTOL, (r, l, "ah")
+            assert_parity(c.download(l, "ah"), T[r][f"ah{l}"], (r, l, "ah"))
             if l < L - 1:
-                assert rel_err(c.download(l, "z"), T[r][f"z{l}"]) < RTOL
-                assert rel_err(c.download(l, "h"), T[r][f"h{l}"]) < RTOL
-                assert rel_err(c.download(l, "aTg"), T[r][f"aTg{l}"]) < RTOL
-                assert rel_err(c.download(l, "g"), T[r][f"g{l}"]) < RTOL
+                assert_parity(c.download(l, "z"), T[r][f"z{l}"], 'c.download(l')
+                assert_parity(c.download(l, "h"), T[r][f"h{l}"], 'c.download(l')
+                assert_parity(c.download(l, "aTg"), T[r][f"aTg{l}"], 'c.download(l')
+                assert_parity(c.download(l, "g"), T[r][f"g{l}"], 'c.download(l')
             if l > 0:
-                assert rel_err(c.download(l, "grad"), T[r][f"grad{l}"]) < RTOL, (r, l, "grad")
-                assert rel_err(c.download(l, "fg"), T[r][f"fg{l}"]) < RTOL
-                assert rel_err(c.download(l - 1, "bg"), T[r][f"bg{l-1}"]) < RTOL
-        assert rel_err(c.download(L - 1, "g"), T[r]["d"]) < RTOL
+                assert_parity(c.download(l, "grad"), T[r][f"grad{l}"], (r, l, "grad"))
+                assert_parity(c.download(l, "fg"), T[r][f"fg{l}"], 'c.download(l')
+                assert_parity(c.download(l - 1, "bg"), T[r][f"bg{l-1}"], 'c.download(l - 1')
+        assert_parity(c.download(L - 1, "g"), T[r]["d"], 'c.download(L - 1')
         a, lo, n = stats[0][r]
         assert abs(a - T[r]["acc"]) < 1e-3 and abs(lo - T[r]["loss"]) < 1e-3 * max(1.0, abs(T[r]["loss"]))
     for l in range(L):
-        assert rel_err(dWs[l], dW[l]) < RTOL, ("dW", l)
+        assert_parity(dWs[l], dW[l], ("dW", l))
     # halo rows are bit-exact copies of the owner's rows (fg[slot(gvid)] == owner.h[lvid(gvid)])
     owner_row = {}
     for r, g in enumerate(gs):
@@ -587,7 +588,7 @@ def test_gcn_epoch_native_partition_and_plan(da):
 def test_gcn_numpy_gnn_fixture(da, golden_dir):
     """Against the reference's own Python GCN (fixture from miscs/numpy-gnn)."""
     import partition_oracle as po
-    from helpers import make_ctx, rel_err
+    from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
     V = int(z["V"])
     g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
@@ -600,21 +601,21 @@ def test_gcn_numpy_gnn_fixture(da, golden_dir):
     ctx.aggregate(0, da.FORWARD)
     ctx.apply_vertex(0, da.FORWARD)
     ctx.aggregate(1, da.FORWARD)
-    assert rel_err(ctx.download(0, "ah"), z["ah0"]) < RTOL
-    assert rel_err(ctx.download(0, "z"), z["z0"]) < RTOL
-    assert rel_err(ctx.download(0, "h"), z["h0"]) < RTOL
-    assert rel_err(ctx.download(1, "ah"), z["ah1"]) < RTOL
+    assert_parity(ctx.download(0, "ah"), z["ah0"], 'ctx.download(0')
+    assert_parity(ctx.download(0, "z"), z["z0"], 'ctx.download(0')
+    assert_parity(ctx.download(0, "h"), z["h0"], 'ctx.download(0')
+    assert_parity(ctx.download(1, "ah"), z["ah1"], 'ctx.download(1')
     ctx.apply_vertex(1, da.FORWARD)
-    assert rel_err(ctx.download(1, "z"), z["z1"]) < RTOL
+    assert_parity(ctx.download(1, "z"), z["z1"], 'ctx.download(1')
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
 def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
     """The reference's Python GCN at the widths of BASELINE configs 2 and 4 (602-128-41 / 300-64-64-25, 1 500 vertices):
     the forward half of the epoch through the C-ABI on the fixture's sampled rows."""
     import partition_oracle as po
-    from helpers import make_ctx, rel_err
+    from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     V = int(z["V"])
     dims = [int(x) for x in z["dims"]]
@@ -636,10 +637,10 @@ def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
         # non-training rows and the 1/(V*0.66) scale, CPU_comm.cpp:126-146) -- the backward half at these widths is
         # checked against the C oracle by test_gcn_epoch_vs_oracle, and the oracle against this fixture on the CPU
         for l in range(L):
-            assert rel_err(ctx.download(l, "ah")[rows], z[f"ah{l}"]) < RTOL, (name, variant, l)
-            assert rel_err(ctx.download(l, "z")[rows], z[f"z{l}"]) < RTOL, (name, variant, l)
+            assert_parity(ctx.download(l, "ah")[rows], z[f"ah{l}"], (name, variant, l))
+            assert_parity(ctx.download(l, "z")[rows], z[f"z{l}"], (name, variant, l))
             if l < L - 1:
-                assert rel_err(ctx.download(l, "h")[rows], z[f"h{l}"]) < RTOL
+                assert_parity(ctx.download(l, "h")[rows], z[f"h{l}"], 'ctx.download(l')
         ctx.close()
 
 
@@ -650,7 +651,7 @@ def test_gcn_numpy_gnn_fixture_backward_half(da, golden_dir):
     CPU_comm.cpp:464-471) and the 1/(V*0.66) scale: those two are checked against the fixture's d with exactly that
     mask and scale applied on the host."""
     import partition_oracle as po
-    from helpers import make_ctx, rel_err
+    from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
     V = int(z["V"])
     g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
@@ -670,26 +671,26 @@ def test_gcn_numpy_gnn_fixture_backward_half(da, golden_dir):
         d = z["d"].astype(np.float64).copy().reshape(-1)
         d[stt * C: stt * C + (V - stt)] = 0.0
         d = d.reshape(V, C) / np.float32(V * 0.66)
-        assert rel_err(ctx.download(1, "g"), d) < RTOL, variant
-        assert rel_err(ctx.weight_grad_get(1), z["ah1"].T @ d) < RTOL, variant
-        assert rel_err(ctx.download(1, "grad"), d @ z["W1"].astype(np.float64).T) < RTOL, variant
+        assert_parity(ctx.download(1, "g"), d, variant)
+        assert_parity(ctx.weight_grad_get(1), z["ah1"].T @ d, variant)
+        assert_parity(ctx.download(1, "grad"), d @ z["W1"].astype(np.float64).T, variant)
         # backward half from the fixture's own gradient
         ctx.upload(1, "grad", z["grad1"].astype(np.float32))
         ctx.aggregate(1, da.BACKWARD)
-        assert rel_err(ctx.download(0, "aTg"), z["aTg0"]) < RTOL, variant
+        assert_parity(ctx.download(0, "aTg"), z["aTg0"], variant)
         ctx.apply_vertex(0, da.BACKWARD)
-        assert rel_err(ctx.download(0, "g"), z["g0"]) < RTOL, variant
-        assert rel_err(ctx.weight_grad_get(0), z["dW0"]) < RTOL, variant
+        assert_parity(ctx.download(0, "g"), z["g0"], variant)
+        assert_parity(ctx.weight_grad_get(0), z["dW0"], variant)
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
 def test_gcn_numpy_gnn_fixture_backward_half_baseline_widths(da, golden_dir, name):
     """The same at the widths of BASELINE configs 2 and 4 (any depth): upload the fixture's complete grad_{L-1}, run the
     backward stages of every layer below through the C-ABI, compare aTg_l, g_l, grad_l (sampled rows) and the complete
     dW_l with the reference's Python GCN."""
     import partition_oracle as po
-    from helpers import make_ctx, rel_err
+    from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     V = int(z["V"])
     dims = [int(x) for x in z["dims"]]
@@ -708,12 +709,12 @@ def test_gcn_numpy_gnn_fixture_backward_half_baseline_widths(da, golden_dir, nam
         ctx.upload(L - 1, "grad", z[f"grad{L-1}_full"])
         for l in range(L - 1, 0, -1):
             ctx.aggregate(l, da.BACKWARD)                       # GA bwd: aTg@(l-1) = A^T grad@l
-            assert rel_err(ctx.download(l - 1, "aTg")[rows], z[f"aTg{l-1}"]) < RTOL, (name, variant, l)
+            assert_parity(ctx.download(l - 1, "aTg")[rows], z[f"aTg{l-1}"], (name, variant, l))
             ctx.apply_vertex(l - 1, da.BACKWARD)                # AV bwd: g, dW, grad@(l-1)
-            assert rel_err(ctx.download(l - 1, "g")[rows], z[f"g{l-1}"]) < RTOL, (name, variant, l)
-            assert rel_err(ctx.weight_grad_get(l - 1), z[f"dW{l-1}"]) < RTOL, (name, variant, l)
+            assert_parity(ctx.download(l - 1, "g")[rows], z[f"g{l-1}"], (name, variant, l))
+            assert_parity(ctx.weight_grad_get(l - 1), z[f"dW{l-1}"], (name, variant, l))
             if l - 1 > 0:
-                assert rel_err(ctx.download(l - 1, "grad")[rows], z[f"grad{l-1}"]) < RTOL, (name, variant, l)
+                assert_parity(ctx.download(l - 1, "grad")[rows], z[f"grad{l-1}"], (name, variant, l))
         ctx.close()
 
 
@@ -956,6 +957,107 @@ def test_gat_engine_epoch_vs_oracle(da, nb):
         assert np.array_equal(ctx.weight_get(l, "a_i"), As[l])
     eng.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["parts_toy60_p2", "parts_toy97_p8_und"])
+@pytest.mark.parametrize("nb", [0, 8])
+def test_gat_epoch_partitions_vs_oracle(da, case, nb):
+    """The reference's GAT prototype ACROSS partitions, end to end: P contexts in one process walk the Engine's GAT stage
+    order (AV -> SC -> AE -> GA, predict, backwards), `z` travels forward into fg_z and `grad` backward into bg_d through
+    the pack / unpack kernels and the halo plans (Engine::scatterGAT / ghostReceiverGAT, gat_ops.cpp:277-435) -- every
+    named tensor of every partition against the oracle's epoch over the same reference-built partitions, ghost rows
+    bit-equal to the owners' rows."""
+    import torch
+    from halo_plan_ref import halo_plan
+    from helpers import assert_parity, make_ctx, oracle_gat_epoch_parts
+    gs, parts = _golden_partitions(case)
+    P, V = len(gs), int(gs[0]["globalVtxCnt"])
+    dims = [20, 16, 6]
+    L = 2
+    rng = np.random.default_rng(11)
+    H0 = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(L)]
+    As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(L)]
+    ctxs, plans = [], []
+    for r, g in enumerate(gs):
+        ctx = make_ctx(da, g, dims, V, gnn=da.GAT, node_id=r, num_nodes=P, options={"spmm_blk_nb": nb})
+        ctx.upload(0, "h", H0[g["localToGlobal"]])
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l in range(L):
+            ctx.weight_set(l, "w", Ws[l])
+            ctx.weight_set(l, "a_i", As[l])
+        pl = halo_plan(g, parts, r, P)
+        for dd in (0, 1):
+            ctx.halo_plan(dd, pl[dd][0], pl[dd][1])
+        ctxs.append(ctx)
+        plans.append(pl)
+
+    def exchange(layer, dd):   # SC of GAT layer `layer` (1-based like the Engine's chunk.layer after incLayerGAT)
+        _, _, ld, _ = ctxs[0].info(layer - 1, "z" if dd == 0 else "grad")
+        send = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][0])) * ld, device="cuda") for r in range(P)]
+        recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][1])) * ld, device="cuda") for r in range(P)]
+        torch.cuda.synchronize()   # (the contexts' streams are non-blocking: torch's zero fills must have landed before a pack kernel writes)
+        for r in range(P):
+            ctxs[r].halo_pack(layer, dd, send[r].data_ptr())
+            ctxs[r].sync()
+        for r in range(P):
+            soff = np.concatenate([[0], np.cumsum([len(x) for x in plans[r][dd][0]])])
+            for p in range(P):
+                roff = np.concatenate([[0], np.cumsum([len(x) for x in plans[p][dd][1]])])
+                n = len(plans[r][dd][0][p])
+                recv[p][roff[r] * ld:(roff[r] + n) * ld] = send[r][soff[p] * ld:(soff[p] + n) * ld]
+        torch.cuda.synchronize()
+        for r in range(P):
+            ctxs[r].halo_unpack(layer, dd, recv[r].data_ptr())
+            ctxs[r].sync()
+
+    for l in range(L):                                  # pipeline.cpp order for GAT (host/engine.cpp: runEpoch)
+        for c in ctxs:
+            c.apply_vertex(l, da.FORWARD)               # AV
+        exchange(l + 1, da.FORWARD)                     # SC
+        for c in ctxs:
+            c.apply_edge(l + 1, da.FORWARD)             # AE
+            c.aggregate(l + 1, da.FORWARD)              # GA
+    for c in ctxs:
+        c.predict_gat(L)
+    for l in range(L - 1, -1, -1):
+        exchange(l + 1, da.BACKWARD)
+        for c in ctxs:
+            c.apply_edge(l + 1, da.BACKWARD)
+            c.aggregate(l + 1, da.BACKWARD)
+            c.apply_vertex(l, da.BACKWARD)
+    T, dWs, das = oracle_gat_epoch_parts(gs, parts, H0, labels, Ws, As)
+    for r, c in enumerate(ctxs):
+        if gs[r]["localVtxCnt"] == 0:
+            continue
+        for l in range(L):
+            for nm in ("z", "ah", "grad", "aTg"):
+                assert_parity(c.download(l, nm), T[r][f"{nm}{l}"], (case, nb, r, l, nm))
+            assert_parity(c.download(l, "az").ravel(), T[r][f"az{l}"], (case, nb, r, l, "az"))
+            assert_parity(c.download(l, "dA").ravel(), T[r][f"dA{l}"], (case, nb, r, l, "dA"))
+            if gs[r]["srcGhostCnt"]:
+                assert_parity(c.download(l, "fg_z"), T[r][f"fg_z{l}"], (case, nb, r, l, "fg_z"))
+            if gs[r]["dstGhostCnt"]:
+                assert_parity(c.download(l, "bg_d"), T[r][f"bg_d{l}"], (case, nb, r, l, "bg_d"))
+    # ghost rows are the owners' rows bit for bit (fg_z[slot(gvid)] == owner.z[lvid(gvid)], bg_d likewise for grad)
+    for l in range(L):
+        g2row = [{}, {}]
+        for r, c in enumerate(ctxs):
+            zz, gg = c.download(l, "z"), c.download(l, "grad")
+            for i, gv in enumerate(gs[r]["localToGlobal"]):
+                g2row[0][int(gv)] = zz[i]
+                g2row[1][int(gv)] = gg[i]
+        for r, c in enumerate(ctxs):
+            if gs[r]["srcGhostCnt"]:
+                assert np.array_equal(c.download(l, "fg_z"), np.stack([g2row[0][int(gv)] for gv in gs[r]["srcGhost"]])), (r, l, "fg_z bits")
+            if gs[r]["dstGhostCnt"]:
+                assert np.array_equal(c.download(l, "bg_d"), np.stack([g2row[1][int(gv)] for gv in gs[r]["dstGhost"]])), (r, l, "bg_d bits")
+    for l in range(L):
+        assert_parity(sum(c.weight_grad_get(l) for c in ctxs), dWs[l], (case, nb, "dW", l))
+        assert_parity(sum(c.weight_grad_get(l, "a_i") for c in ctxs).ravel(), das[l], (case, nb, "da", l), rtol=5e-4, atol_frac=5e-5)
+    for c in ctxs:
+        c.close()
 
 
 def test_fill_uniform_matches_host_twin(da):

@@ -97,7 +97,7 @@ def _oracle_epoch_any_depth(z, g):
     return out
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
 def test_gcn_epoch_matches_numpy_gnn_at_baseline_widths(golden_dir, name):
     """The same pin at the widths of BASELINE configs 2 and 4 (602-128-41; 300-64-64-25, three layers), 1 500 vertices:
     every intermediate tensor on the fixture's sampled rows and both/all three complete weight gradients against the

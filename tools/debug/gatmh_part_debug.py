@@ -54,6 +54,7 @@ def run(P, dims, heads, sweep, rows=0, sflags=0, serial=False):
         _, _, ld, _ = ctxs[0].info(layer, src_name)
         send = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][0])) * ld, device="cuda") for r in range(P)]
         recv = [torch.zeros(max(1, sum(len(x) for x in plans[r][dd][1])) * ld, device="cuda") for r in range(P)]
+        torch.cuda.synchronize()   # (the contexts' streams are non-blocking: torch's zero fills must have landed before a pack kernel writes)
         for r in range(P):
             ctxs[r].halo_pack_tensor(layer, src_name, dd, send[r].data_ptr())
             ctxs[r].sync()
@@ -78,6 +79,15 @@ def run(P, dims, heads, sweep, rows=0, sflags=0, serial=False):
             c.aggregate(l + 1, da.FORWARD)
             if serial:
                 c.sync()
+        if l == 1 and P == 4 and not serial:
+            for c in ctxs: c.sync()
+            conc = [(c.download(1, "o").copy(), c.download(1, "den").copy(), c.download(1, "m").copy()) for c in ctxs]
+            for c in ctxs:
+                c.aggregate(l + 1, da.FORWARD); c.sync()
+            for r, c in enumerate(ctxs):
+                o2, d2, m2 = c.download(1, "o"), c.download(1, "den"), c.download(1, "m")
+                badrows = np.where(np.abs(conc[r][0] - o2).max(1) > 1e-6)[0]
+                print("rank", r, "rows differing concurrent vs serial rerun:", len(badrows), list(badrows[:20]), "den diff rows", int((np.abs(conc[r][1]-d2).max(1) > 1e-6).sum()), "m diff rows", int((np.abs(conc[r][2]-m2).max(1) > 0).sum()))
     for c in ctxs:
         c.predict_gat(L)
     for l in range(L - 1, -1, -1):
@@ -104,10 +114,11 @@ def run(P, dims, heads, sweep, rows=0, sflags=0, serial=False):
 
 
     for l in range(L):
-        for nm, ref in (("z", fws[l]["Z"]), ("o", fws[l]["O"]), ("t", grads[l]["t"]), ("del", grads[l]["d_el"]), ("der", grads[l]["d_er"]), ("dz", grads[l]["dZ"])):
+        for nm, ref in (("z", fws[l]["Z"]), ("o", fws[l]["O"]), ("t", grads[l]["t"]), ("del", grads[l]["d_el"]), ("der", grads[l]["d_er"]), ("dz", grads[l]["dZ"]), ("m+lden", None), ("do", None)):
+            if ref is None: continue
             got = gathered(l, nm)
             per_rank = [float(np.abs(got[g["localToGlobal"]] - ref[g["localToGlobal"]]).max() / np.abs(ref).max()) for g in gs]
-            if nm == "o": print(P, sweep, rows, sflags, serial, l, nm, "%.2e" % rel_err(got, ref), ["%.1e" % x for x in per_rank])
+            if rel_err(got, ref) > 1e-3: print(P, sweep, rows, sflags, serial, l, nm, "%.2e" % rel_err(got, ref), ["%.1e" % x for x in per_rank])
         lse = np.log(gathered(l, "den").astype(np.float64)) + gathered(l, "m")
         if 0: print("   lse err", np.abs(lse - (np.log(fws[l]["den"]) + fws[l]["m"])).max())
     l = 1
@@ -117,7 +128,7 @@ def run(P, dims, heads, sweep, rows=0, sflags=0, serial=False):
         el = fws[l]["el"]; er = fws[l]["er"]
         for r, g in enumerate(gs):
             N = int(g["localVtxCnt"])
-            l2g = g["localToGlobal"]; gh = g["srcGhost"] if "srcGhost" in g else None
+            l2g = g["localToGlobal"]
             ptr = g["colPtr"].astype(np.int64); idx = g["rowIdx"].astype(np.int64)
             allg = np.concatenate([l2g, np.asarray(g["srcGhost"], np.int64)])
             mg = ctxs[r].download(l, "m"); dg = ctxs[r].download(l, "den")
@@ -132,11 +143,15 @@ def run(P, dims, heads, sweep, rows=0, sflags=0, serial=False):
                 sc = el[src] + er[gv][None, :]; sc = np.where(sc > 0, sc, 0.2 * sc)
                 sself = el[gv] + er[gv]; sself = np.where(sself > 0, sself, 0.2 * sself)
                 p = np.exp(sc - mg[v][None, :])
-                if nbad <= 6:
-                    print("rank", r, "row", v, "err %.2e" % e, "den_gpu", dg[v][:K], "self", np.exp(sself - mg[v]), "local", p[loc].sum(0), "ghost", p[~loc].sum(0), "nl", loc.sum(), "ng", (~loc).sum())
-            print("rank", r, "bad rows", nbad, "of", N)
+                if nbad <= 4 and r in (1, 2):
+                    print("rank", r, "row", v, "err %.2e" % e, "den_gpu", dg[v][:K], "self", np.exp(sself - mg[v]), "local", p[loc].sum(0), "ghost", p[~loc].sum(0), "nl", loc.sum(), "ng", (~loc).sum(), "ghost ids", idx[ptr[v]:ptr[v+1]][~loc] - N)
+            print("rank", r, "bad rows", nbad, "of", N, "Gsrc", len(g["srcGhost"]))
+    print("gate timeouts", [c.get_option("spmm_gate_timeouts") for c in ctxs], "ungated", [c.get_option("spmm_ungated_launches") for c in ctxs])
     for c in ctxs:
         c.close()
 
-rows = int(sys.argv[1]); serial = bool(int(sys.argv[2]))
-run(4, [24, 32, 8], [4, 2], 1, rows=rows, serial=serial)
+sweep = int(sys.argv[1]); serial = bool(int(sys.argv[2])); sflags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+for P in (2, 4):
+    for dims, heads in (([24, 32, 8], [4, 2]), ([24, 128, 6], [8, 1])):
+        run(P, dims, heads, sweep, serial=serial, sflags=sflags)
+print("done", sweep, serial)
