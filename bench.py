@@ -355,7 +355,7 @@ def main():
     if tf_mode:
         edges_per_epoch = nl * E_in + nl * E_out
     if gat:                                                  # 2 fwd (CSC) + 2 bwd x (CSR + CSC) aggregations
-        edges_per_epoch = 4 * E_in + 2 * E_out               # (gatmh: softmax passes re-walk the edges; same count used)
+        edges_per_epoch = 4 * E_in + 2 * E_out               # (gatmh: the count of round 1-4's six passes is kept so that edges/s stays comparable)
     value = edges_per_epoch / (ms_per_step * 1e-3)
 
     # ---- roofline of the dominant kernel (K1 SpMM): HIP events recorded during the timed steps ----
@@ -491,6 +491,7 @@ def main():
                  "halo_deferred_ms_per_epoch_max_rank": float((A[:, 7] / args.steps).max()),
                  "spmm_beside_halo_ms_per_epoch_max_rank": float((A[:, 9] / args.steps).max()),
                  "reserve_probe": reserve_probe, "preflight": preflight,
+                 "projected": scaling_projection_for(args.workload, args.graph, world),
                  "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS")},
                  "note": "halo = one all-to-all-v of h (forward) and one of grad (backward) per epoch, " + str(DIMS[1]) + " floats per ghost row; "
                          "ms are HIP-event times on the comm stream (pack + grouped ncclSend/ncclRecv + unpack), overlapped with the interior-source SpMM blocks"}
@@ -733,21 +734,31 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
                            "gathered_bytes_per_epoch": int(gathered), "gathered_TBps": round(gathered / t / 1e12, 3),
                            "gathered_frac_of_achievable_hbm_6.3_TBps": round(gathered / t / 1e12 / 6.3, 4)}
     if gnn == "gatmh" and fam["spmm"][1]:
-        # compulsory bytes of the epoch's six edge passes (forward, destination-side and source-side backward sweeps of both
-        # layers: 4 over the CSC, 2 over the CSR), each: the index stream once + pointers + one read and one write of an
-        # N x ld row tensor (z / dO in, o / dz out; the per-(vertex, head) scores and statistics are K floats per row)
+        # compulsory bytes of the epoch's FOUR edge passes (round 5: forward over the CSC and source-side backward over the CSR
+        # of both layers; the destination-side backward pass is a row-wise kernel since the forward carries the positive-branch
+        # sums), each: the index stream once + pointers + one read and one write of an N x ld row tensor (z / dO in, o / dz
+        # out) + the per-(vertex, head) scores and statistics (K floats x 4 per row); plus the row-wise stage's three reads
+        # of an N x ld tensor (dO, o, op) and the forward's second output (op)
         lds = [(DIMS_[1] + 31) // 32 * 32, (DIMS_[2] + 31) // 32 * 32]
+        swept = bool(ctx.get_option("gatmh_sweep"))
         algo = 0
         for ld_, K_ in ((lds[0], 8), (lds[1], 1)):
-            for nnz in (nnz_in, nnz_in, nnz_out):
+            for nnz in (nnz_in, nnz_out):
                 algo += 4 * nnz + 8 * (N + 1) + 2 * 4 * N * ld_ + 4 * 4 * N * K_
+            algo += 4 * 4 * N * ld_
+        gathered = 4 * (nnz_in + nnz_out) * (lds[0] + lds[1])
         t = fam["spmm"][0] / steps * 1e-3
         res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": None,
                            "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
-                           "kernel": "gatmh_*_blocked_kernel family + reduce kernels (six edge passes per epoch)",
-                           "gathered_bytes_per_epoch": int(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) ),
-                           "l1_path_frac": round(4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1]) / t / 1e12 / 37.7, 4)}
+                           "kernel": ("gatmh_forward_sweep_kernel + gatmh_src_sweep_kernel on K1s's skeleton (four edge passes per epoch: single-pass "
+                                      "softmax against an upper-bound shift; t / der row-wise from the forward's positive-branch sums)") if swept else
+                                     "gatmh_*_blocked_kernel family + reduce kernels (six edge passes per epoch)",
+                           "edge_passes_per_epoch": 4 if swept else 6,
+                           "gathered_bytes_per_epoch": int(gathered if swept else 4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1])),
+                           "l1_path_frac": round((gathered if swept else 4 * (3 * nnz_in * lds[0] + 3 * nnz_in * lds[1])) / t / 1e12 / 37.7, 4),
+                           "note": "round 4's line counted six passes (3.94 GB, 264 GB gathered); with the sweep forms the epoch needs four: "
+                                   "achieved / frac are against the four-pass figure, l1_path_frac against the rows actually gathered"}
     if gnn == "gcn" and dims is not None:
         # the same partition in the transform-first order (opt-in gcn_transform_first=2, not the reference's schedule): the layers
         # whose input is wider than their output gather the narrower rows -- on config 4 the 300-float launch becomes a 64-float one
@@ -766,6 +777,24 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
     eng.close()
     ctx.close()
     return res
+
+
+def scaling_projection_for(workload, graph, world):
+    """The epoch this repo expected of a `world`-GPU run BEFORE it ran (tools/scaling_projection.py, written in round 5 from
+    per-rank measurements on one GPU + 153 GB/s per xGMI link): printed beside the measurement so that the first real
+    multi-GPU record carries prediction and measurement side by side."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_scaling_projection.json")))
+        case = pj["cases"][f"{workload}:{graph}"]
+        e = case["by_P"][str(world)]
+        return {"available": True, "source": "profiles/r05_scaling_projection.json (tools/scaling_projection.py; projection, not a measurement)",
+                "projected_epoch_ms": e["projected_epoch_ms"], "compute_ms_max_rank": e["compute_ms_max"], "compute_ms_mean": e["compute_ms_mean"],
+                "exposed_halo_ms_max_rank": e["exposed_halo_ms_max"], "allreduce_ms": e["allreduce_ms"],
+                "halo_bytes_per_exchange_max_peer": e["halo_bytes_per_exchange_max_peer"], "nnz_in_max_over_mean": e["nnz_in_max_over_mean"],
+                "single_gpu_epoch_ms": case.get("single_gpu_epoch_ms"), "projected_speedup": e.get("projected_speedup"),
+                "model": e["model"]}
+    except (OSError, KeyError, ValueError) as ex:
+        return {"available": False, "why": f"no projection on record for {workload}:{graph} x{world} ({type(ex).__name__})"}
 
 
 def set_gloo_transport(ctx, dist, torch, rank, world):

@@ -56,3 +56,11 @@ def test_bench_multirank_dry_run_on_one_gpu(world):
     fr = m["halo_overlap_fraction_per_rank"]
     assert len(fr) == world and all(f is None or 0.0 <= f <= 1.0 for f in fr)
     assert m["halo_deferred_ms_per_epoch_max_rank"] >= 0 and m["spmm_beside_halo_ms_per_epoch_max_rank"] >= 0
+    # round 5: the written expectation travels with the record (projection of tools/scaling_projection.py for this workload,
+    # graph and world size when one is on file: world 2 and 4 are; 3 is not and must say so)
+    pj = m["projected"]
+    assert isinstance(pj, dict) and "available" in pj
+    if pj["available"]:
+        assert pj["projected_epoch_ms"] > 0 and pj["compute_ms_max_rank"] > 0 and pj["model"]["link_GBps"] == 153.0
+    else:
+        assert "why" in pj
