@@ -460,6 +460,10 @@ def main():
         ctx.set_option("gcn_cache_ah0", 0)
     gates = {"timeouts": int(ctx.get_option("spmm_gate_timeouts")), "ungated_launches": int(ctx.get_option("spmm_ungated_launches")),
              "spmm_sweep_reserve_cus": int(ctx.get_option("spmm_sweep_reserve_cus")),
+             # K1s's placement assumption (workgroup id & 7 = XCD, eight XCDs), checked once per context at dory_create; when it
+             # fails the gated / ungated form is chosen by measurement (policy 0 / 8; -1 = nothing to decide)
+             "xcd_mapping_ok": bool(ctx.get_option("spmm_xcd_mapping_ok")), "xcd_count": int(ctx.get_option("spmm_xcd_count")),
+             "xcd_policy": int(ctx.get_option("spmm_xcd_policy")),
              "note": "K1s sweeps whose workgroups were not co-resident within the polling bound (then the launch and the next 16 "
                      "ran ungated: same results, unsynchronised rate); 0 / 0 is the healthy state"}
 

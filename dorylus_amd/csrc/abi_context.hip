@@ -179,6 +179,27 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_sweep_layout"] = 3;         // K1s layout: 1 = spread the source rows over the blocks at random, 2 = deal the rows by degree (0: K1b's order -- graphs without structure only)
     c->opt["spmm_sweep_window_kb"] = 0;      // K1s: source window per block; 0 = 2432 KB (two live windows in one XCD's 4 MB L2), 3584 KB for partitions of <= 4 rows per lane group
     c->cus_per_xcd = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
+    {   // K1s's placement assumption (ctx.hpp): workgroup id & 7 = XCD, eight XCDs
+        const uint32_t PG = 2048;
+        uint32_t *dx = nullptr;
+        std::vector<uint32_t> hx(PG, 0xFFu);
+        if (hipMalloc((void **)&dx, PG * sizeof(uint32_t)) == hipSuccess) {
+            bool ran = launch_xcd_probe(dx, PG, c->compute) == hipSuccess && hipStreamSynchronize(c->compute) == hipSuccess &&
+                       hipMemcpy(hx.data(), dx, PG * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(dx);
+            // what K1s needs: workgroups with the same id & 7 share an XCD, the eight residues sit on eight different XCDs
+            // (the dispatcher's round robin may start anywhere: the residue -> XCD map is a rotation, not the identity)
+            uint32_t seen = 0, match = 0;
+            for (uint32_t i = 0; i < PG; ++i) { if (hx[i] < 16) seen |= 1u << hx[i]; match += hx[i] == hx[i & 7u]; }
+            uint32_t firsts = 0;
+            for (uint32_t r = 0; r < 8; ++r) if (hx[r] < 16) firsts |= 1u << hx[r];
+            c->xcd_count = (uint32_t)__builtin_popcount(seen);
+            c->xcd_mapping_ok = ran && match == PG && c->xcd_count == 8 && __builtin_popcount(firsts) == 8;
+        } else {
+            c->xcd_mapping_ok = false;
+        }
+    }
+    c->opt["spmm_xcd_assume_mismatch"] = 0;  // testing: treat the placement check as failed (the gated / ungated choice is then made by measurement)
     c->opt["spmm_slab"] = 0;
     c->opt["spmm_order"] = 1;    // K1: rows longest first -- 1 = when the degrees are skewed (max > 8 x mean), 2 = always, 0 = never
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
@@ -818,6 +839,11 @@ int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     // read-only counters of the K1s gates (device words that outlive the launches): timeouts = a sweep's workgroups were
     // not co-resident within the polling bound; ungated launches = launches that ran without gates while the context
     // backed off after a timeout (same results, unsynchronised rate)
+    if (key && value && !strcmp(key, "spmm_xcd_mapping_ok")) { *value = c->xcd_mapping_ok ? 1 : 0; return DORY_OK; }   // read-only: dory_create's check
+    if (key && value && !strcmp(key, "spmm_xcd_count")) { *value = c->xcd_count; return DORY_OK; }
+    if (key && value && !strcmp(key, "spmm_xcd_policy")) { *value = c->xcd_policy; return DORY_OK; }                  // -1 undecided / not needed, 0 gated, 8 ungated
+    if (key && value && !strcmp(key, "spmm_xcd_gated_us")) { *value = (int64_t)(c->xcd_gated_ms * 1e3f); return DORY_OK; }
+    if (key && value && !strcmp(key, "spmm_xcd_ungated_us")) { *value = (int64_t)(c->xcd_ungated_ms * 1e3f); return DORY_OK; }
     if (key && value && (!strcmp(key, "spmm_gate_timeouts") || !strcmp(key, "spmm_ungated_launches"))) {
         uint32_t st[4] = {0, 0, 0, 0};
         HIPCK(c, hipStreamSynchronize(c->compute));

@@ -149,13 +149,34 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             if (S.nslots && (rc = ensure_scratch(c, (size_t)S.nslots * a.ld * sizeof(float)))) return rc;   // pieces of split rows
             Timed t(c, "spmm", c->compute);
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
-            const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+            uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
             SweepCtl ctl;
             ctl.force_r = force_r;
             ctl.pair = (int)c->opt["spmm_sweep_pair"];
             ctl.stat = c->sweep_stat;
             ctl.loader = c->opt["spmm_sweep_loader"] != 0;
             SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
+            // placement check failed (ctx.hpp): gates would synchronise workgroups that do not share an L2.  Decide once, by
+            // measurement, on a launch that may be repeated (it writes, does not accumulate): gated against ungated
+            if ((!c->xcd_mapping_ok || c->opt["spmm_xcd_assume_mismatch"]) && !(sflags & 8u)) {
+                if (c->xcd_policy < 0 && !c->capturing && !a.accumulate && !c->halo_pending) {
+                    hipEvent_t e0, e1, e2;
+                    HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1)); HIPCK(c, hipEventCreate(&e2));
+                    const uint32_t hi = two ? S.nb_local : S.nb;
+                    HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags | 8u, c->scratch));   // (warm: layout, code)
+                    HIPCK(c, hipEventRecord(e0, c->compute));
+                    HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags, c->scratch));
+                    HIPCK(c, hipEventRecord(e1, c->compute));
+                    HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags | 8u, c->scratch));
+                    HIPCK(c, hipEventRecord(e2, c->compute));
+                    HIPCK(c, hipEventSynchronize(e2));
+                    (void)hipEventElapsedTime(&c->xcd_gated_ms, e0, e1);
+                    (void)hipEventElapsedTime(&c->xcd_ungated_ms, e1, e2);
+                    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+                    c->xcd_policy = c->xcd_gated_ms <= c->xcd_ungated_ms ? 0 : 8;
+                }
+                sflags |= c->xcd_policy == 0 ? 0u : 8u;      // undecided (recording, accumulating caller): ungated, never a timeout
+            }
             if (two) {
                 // under an exchange in flight the RCCL kernels need CUs of their own
                 const uint32_t reserve = c->halo_pending ? (uint32_t)c->opt["spmm_sweep_reserve_cus"] : 0u;
@@ -346,7 +367,8 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                     SweepCtl ctl;
                     ctl.stat = c->sweep_stat;
                     uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
-                    const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+                    const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"] |
+                                            (((!c->xcd_mapping_ok || c->opt["spmm_xcd_assume_mismatch"]) && c->xcd_policy != 0) ? 8u : 0u);
                     const float *a_l = c->weights[fl]["a_l"].d;
                     HIPCK(c, launch_gatmh_sweep_begin(c->N, c->Gsrc, K, z->ld, el->ld, Sf, el->d, fgel->d, c->scratch, c->compute));
                     if (two) {
@@ -441,7 +463,8 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             SweepCtl ctl;
             ctl.stat = c->sweep_stat;
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
-            const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
+            const uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"] |
+                                    (((!c->xcd_mapping_ok || c->opt["spmm_xcd_assume_mismatch"]) && c->xcd_policy != 0) ? 8u : 0u);
             {
                 Timed t(c, "spmm", c->compute);
                 HIPCK(c, launch_gatmh_src_sweep_begin(c->N, c->Gdst, K, z->ld, el->ld, So, st4, reinterpret_cast<const float4 *>(bgst->d), lds4,

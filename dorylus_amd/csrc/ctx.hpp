@@ -134,6 +134,14 @@ struct dory_ctx {
     bool blkIn_built = false, blkOut_built = false;
     bool blkIn_na = false, blkOut_na = false;   // K1b not applicable (too many source blocks): use K1
     uint32_t cus_per_xcd = 32;                  // K1s: workgroups per sweep
+    // K1s's placement assumption, checked once per context (dory_create: HW_REG_XCC_ID of 2048 probe workgroups -- equal
+    // id & 7 => same XCD, the eight residues on eight XCDs).  When it does not hold (a CPX / NPS-partitioned or CU-masked device) the gates
+    // synchronise workgroups that do not share an L2: the first idempotent K1s launch is then run gated and ungated, timed,
+    // and the faster form kept (xcd_policy: -1 not decided, 0 gated, 8 ungated = the SWEEP flag)
+    bool xcd_mapping_ok = true;
+    uint32_t xcd_count = 8;
+    int xcd_policy = -1;
+    float xcd_gated_ms = 0.f, xcd_ungated_ms = 0.f;
     uint32_t *sweep_stat = nullptr;             // K1s: SWEEP_STAT_WORDS device words that outlive the launches: gate timeouts, back-off horizon of
                                                 // the launches that run alone, ungated launches, back-off horizon of the launches
                                                 // beside an exchange, launch number (bumped on the device: hipGraph replays advance
@@ -258,6 +266,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
 hipError_t launch_spmm_sweep_combine(const SpmmArgs &a, const BlockedAdj &B, const float *row_scale, const float *split_partial,
                                      hipStream_t s);
 hipError_t launch_occupy_cus(uint32_t workgroups, uint64_t usec, hipStream_t s);   // diagnostic (dory_debug_occupy_cus)
+hipError_t launch_xcd_probe(uint32_t *xcc /*grid words*/, uint32_t grid, hipStream_t s);   // HW_REG_XCC_ID of every probe workgroup
 size_t blocked_partial_bytes(const SpmmArgs &a, const BlockedAdj &B);
 hipError_t launch_spmm_blocked(const SpmmArgs &a, const BlockedAdj &B, float *partial, int group /*8|16|32 lanes per row*/,
                                const float *row_scale /*nullable: unit edge weights, per-row factor*/, hipStream_t s);

@@ -692,4 +692,14 @@ hipError_t launch_occupy_cus(uint32_t workgroups, uint64_t usec, hipStream_t s) 
     return hipGetLastError();
 }
 
+// ---- which XCD does workgroup i run on?  K1s assumes i & 7 (for speed only); dory_create checks it once per context ----
+__global__ void xcd_probe_kernel(uint32_t *xcc) {
+    const uint32_t id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // HW_REG_XCC_ID, bits [3:0]
+    if (threadIdx.x == 0) xcc[blockIdx.x] = id & 15u;
+}
+hipError_t launch_xcd_probe(uint32_t *xcc, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(grid), dim3(64), 0, s, xcc);
+    return hipGetLastError();
+}
+
 }  // namespace dory

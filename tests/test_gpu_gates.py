@@ -227,3 +227,31 @@ def _one_epoch(ctx, da):
     ctx.aggregate(1, da.BACKWARD)
     ctx.apply_vertex(0, da.BACKWARD)
     ctx.weight_update(0)
+
+
+def test_xcd_placement_check_and_measured_fallback():
+    """K1s assumes workgroup id & 7 = XCD and eight XCDs.  dory_create checks it (HW_REG_XCC_ID of 2 048 probe workgroups); on
+    this device the check must hold.  When it does not (forced here by option), the first repeatable K1s launch runs gated
+    and ungated, the faster form is kept (spmm_xcd_policy 0 / 8), nothing is counted as a gate timeout, and the bits are
+    those of the normal context."""
+    import dorylus_amd as da
+    V, E, F = 60000, 1500000, 128
+    g = _graph(V, E, 9)
+    ctx = _ctx(da, g, V, F)
+    assert ctx.get_option("spmm_xcd_mapping_ok") == 1 and ctx.get_option("spmm_xcd_count") == 8
+    ctx.aggregate(0, da.FORWARD)
+    assert ctx.get_option("spmm_xcd_policy") == -1          # nothing to decide
+    ref = ctx.download(0, "ah")
+    ctx.close()
+    ctx = _ctx(da, g, V, F)
+    ctx.set_option("spmm_xcd_assume_mismatch", 1)
+    for _ in range(3):
+        ctx.aggregate(0, da.FORWARD)
+    pol = ctx.get_option("spmm_xcd_policy")
+    assert pol in (0, 8)
+    assert ctx.get_option("spmm_xcd_gated_us") > 0 and ctx.get_option("spmm_xcd_ungated_us") > 0
+    # the choice follows the measurement
+    assert (pol == 0) == (ctx.get_option("spmm_xcd_gated_us") <= ctx.get_option("spmm_xcd_ungated_us"))
+    assert np.array_equal(ctx.download(0, "ah"), ref)
+    assert ctx.get_option("spmm_gate_timeouts") == 0 and ctx.get_option("spmm_ungated_launches") == 0
+    ctx.close()
