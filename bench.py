@@ -153,6 +153,23 @@ def halo_selfcheck(ctx, g, da):
     return bool(ok)
 
 
+def halo_selfcheck_gat(ctx, g, da, gnn):
+    """the same for the GAT orders (Engine::scatterGAT / ghostReceiverGAT, gat_ops.cpp:277-435): `z` travels forward into
+    fg_z, `grad` backward into bg_d (the multi-head extension ships dO and its statistics inside its backward aggregate,
+    so only its forward exchange is checked here); every received row must be the owner's row bit for bit."""
+    ctx.fill_uniform(0, "z", 7, -1.0, 1.0, g["localToGlobal"])
+    ctx.halo_exchange(1, da.FORWARD)
+    ctx.sync()
+    zc = ctx.info(0, "z")[1]
+    ok = np.array_equal(ctx.download(0, "fg_z"), splitmix_uniform(7, g["srcGhost"], zc))
+    if gnn == "gat":
+        ctx.fill_uniform(0, "grad", 9, -1.0, 1.0, g["localToGlobal"])
+        ctx.halo_exchange(1, da.BACKWARD)
+        ctx.sync()
+        ok = ok and np.array_equal(ctx.download(0, "bg_d"), splitmix_uniform(9, g["dstGhost"], ctx.info(0, "grad")[1]))
+    return bool(ok)
+
+
 def git_blob_sha1(path):
     """what `git hash-object` prints (the GPU box has no .git): sha1("blob <len>\\0" + content)"""
     import hashlib
@@ -290,8 +307,8 @@ def main():
             ctx.comm_init(idt.cpu().numpy(), rank, world)
     halo_ok = None
     run_stage["name"] = "halo self-check (two exchanges + overlapped / sequential aggregates)"
-    if world > 1 and not gat:
-        flag = torch.tensor([1 if halo_selfcheck(ctx, g, da) else 0], dtype=torch.int32, device=tdev)
+    if world > 1:
+        flag = torch.tensor([1 if (halo_selfcheck_gat(ctx, g, da, args.gnn) if gat else halo_selfcheck(ctx, g, da)) else 0], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         halo_ok = bool(flag.item())
         if not halo_ok:

@@ -64,3 +64,17 @@ def test_bench_multirank_dry_run_on_one_gpu(world):
         assert pj["projected_epoch_ms"] > 0 and pj["compute_ms_max_rank"] > 0 and pj["model"]["link_GBps"] == 153.0
     else:
         assert "why" in pj
+
+
+def test_bench_multirank_gat_dry_run_checks_its_halo():
+    """--gnn gat with N > 1: the halo self-check (z forward into fg_z, grad backward into bg_d, bit-equal to the owners' rows)
+    runs before anything is timed (round 5; it was skipped for the GAT orders before)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--gnn", "gat",
+           "--device", "0", "--steps", "2", "--warmup", "1", "--scale", "0.08", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["halo_selfcheck"] is True and d["ms_per_step"] > 0

@@ -186,3 +186,133 @@ def test_engine_epochs_two_processes_one_gpu(name):
         assert ok_calls, (rank, calls)
         bad = {k: e for k, e in errs.items() if not e < RTOL}
         assert not bad, (rank, bad)
+
+
+def _worker_gat(rank, world, port, case, q):
+    """the reference's GAT prototype as `world` processes on one GPU: dory_engine_run with DORY_GAT, z forward / grad backward
+    over the host transport (Engine::scatterGAT / ghostReceiverGAT, gat_ops.cpp:277-435)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import torch.distributed as dist
+        import dorylus_amd as da
+        from helpers import elem_err, oracle_gat_epoch_parts, rel_err
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dims, V, E = case["dims"], case["V"], case["E"]
+        rng = np.random.default_rng(case["seed"])
+        s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+        src, dst = np.concatenate([s, d]), np.concatenate([d, s])
+        parts = (np.arange(V, dtype=np.int64) * world // V).astype(np.int32) if case["parts"] == "block" else rng.integers(0, world, V).astype(np.int32)
+        H0 = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+        labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+        L = len(dims) - 1
+        Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(L)]
+        As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(L)]
+        all_parts = [da.Partition.build(src, dst, parts, r, world) for r in range(world)]
+        gs = [p.view() for p in all_parts]
+        part, g = all_parts[rank], gs[rank]
+        ctx = da.Context(0)
+        ctx.configure(da.GAT, dims, V, rank, world)
+        for k, v in case.get("opts", {}).items():
+            ctx.set_option(k, v)
+        part.upload(ctx, parts)
+        ctx.preallocate()
+        ctx.upload(0, "h", H0[g["localToGlobal"]])
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l in range(L):
+            ctx.weight_set(l, "w", Ws[l])
+            ctx.weight_set(l, "a_i", As[l])
+        ctx.adam_config(0.01)
+        calls = {"a2a": 0, "ar": 0}
+
+        def alltoallv(send, sc, so, recv, rc, ro):
+            calls["a2a"] += 1
+            reqs, keep = [], []
+            for p in range(world):
+                if p == rank:
+                    continue
+                if rc[p]:
+                    t = torch.empty(int(rc[p]), dtype=torch.float32)
+                    keep.append((t, int(ro[p]), int(rc[p])))
+                    reqs.append(dist.irecv(t, p))
+                if sc[p]:
+                    reqs.append(dist.isend(torch.from_numpy(send[int(so[p]):int(so[p] + sc[p])].copy()), p))
+            for r_ in reqs:
+                r_.wait()
+            for t, o, n in keep:
+                recv[o:o + n] = t.numpy()
+
+        def allreduce(buf):
+            calls["ar"] += 1
+            t = torch.from_numpy(buf.copy())
+            dist.all_reduce(t)
+            buf[:] = t.numpy()
+        ctx.set_host_transport(alltoallv, allreduce)
+        eng = da.NativeEngine(ctx)
+        eng.run(1)
+        ctx.sync()
+        T, dWs, das = oracle_gat_epoch_parts(gs, parts, H0, labels, Ws, As)
+        errs = {}
+        if g["localVtxCnt"]:
+            for l in range(L):
+                for nm in ("z", "ah", "grad", "aTg"):
+                    a, b = ctx.download(l, nm), T[rank][f"{nm}{l}"]
+                    errs[f"{nm}{l}"] = rel_err(a, b)
+                    # element-wise criterion (tests/helpers.py) on the activations; grad = softmax - onehot is a difference of O(1)
+                    # numbers (its entries go down to 1e-10 on confidently classified rows while its rounding error stays at
+                    # eps x 1), so it and what is aggregated from it keep the max-norm bound
+                    if nm in ("z", "ah"):
+                        errs[f"{nm}{l}_elem"] = 1e-4 * elem_err(a, b)
+                if g["srcGhostCnt"]:
+                    errs[f"fg_z{l}"] = rel_err(ctx.download(l, "fg_z"), T[rank][f"fg_z{l}"])
+                if g["dstGhostCnt"]:
+                    errs[f"bg_d{l}"] = rel_err(ctx.download(l, "bg_d"), T[rank][f"bg_d{l}"])
+        for l in range(L):
+            errs[f"dW{l}"] = rel_err(ctx.weight_grad_get(l), dWs[l])          # the all-reduced sum, on every rank
+        # ghost rows of the last layer's z: the owner's bits
+        own = ctx.download(L - 1, "z")
+        allz = [None] * world
+        dist.all_gather_object(allz, (g["localToGlobal"], own))
+        if g["srcGhostCnt"]:
+            g2row = {int(gv): zz[i] for l2g, zz in allz for i, gv in enumerate(l2g)}
+            want = np.stack([g2row[int(gv)] for gv in g["srcGhost"]])
+            errs["fg_z_bits"] = 0.0 if np.array_equal(ctx.download(L - 1, "fg_z"), want) else 1.0
+        ok_calls = calls["a2a"] == 2 * L and calls["ar"] >= L
+        eng.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, errs, ok_calls, calls))
+    except Exception:
+        q.put((rank, traceback.format_exc(), False, None))
+
+
+@pytest.mark.parametrize("world,parts", [(2, "block"), (3, "hash")])
+def test_gat_prototype_engine_epoch_processes_one_gpu(world, parts):
+    import torch.multiprocessing as mp
+    case = dict(dims=[24, 16, 6], V=2400, E=26000, seed=6, parts=parts, opts={"spmm_blk_nb": 8})
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker_gat, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, errs, ok_calls, calls in sorted(res, key=lambda t: t[0]):
+        assert isinstance(errs, dict), f"rank {rank} failed:\n{errs}"
+        assert ok_calls, (rank, calls)
+        bad = {k: e for k, e in errs.items() if not e < RTOL}
+        assert not bad, (rank, bad)
