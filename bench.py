@@ -608,7 +608,8 @@ def rank_of_8_epoch(da, workload, steps, warmup):
 def first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev):
     """N > 1, before any partition is built: the two collectives of the path on a 64-vertex-per-rank toy partition, through
     the same C-ABI calls the epoch uses -- a grouped ncclSend/ncclRecv exchange of 1 MB per peer (dory_halo_exchange, both
-    directions) and a 311 KB ncclAllReduce (dory_weight_update) -- under a 60 s watchdog that names the call it was in.
+    directions) and a 311 KB ncclAllReduce (dory_weight_update) -- under a per-stage watchdog (DORY_PREFLIGHT_STAGE_S, 120 s) that
+    names the call it was in and the seconds every earlier stage took.
     A first run on real xGMI then fails here, in seconds and with the failing call's name, not minutes later inside a
     timed region.  Results are checked (ghost rows bit-equal to the owners', gradient sum exact).  Over --transport host the
     same calls run with the bytes through gloo."""
@@ -616,14 +617,22 @@ def first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev):
     stage = {"name": "start", "t0": time.time()}
     done = threading.Event()
 
+    # the limit is PER STAGE (re-armed by enter()): a slow but healthy cold start -- RCCL's topology detection and lazy channel
+    # setup on eight GPUs -- is many stages of a few seconds each, a hang is one stage that never ends
+    limit = float(os.environ.get("DORY_PREFLIGHT_STAGE_S", "120"))
+    stage["log"] = []
+
     def watchdog():
-        if not done.wait(60.0):
-            sys.stderr.write("bench.py preflight: rank %d STUCK for 60 s in: %s\n" % (rank, stage["name"]))
-            sys.stderr.flush()
-            os._exit(3)
+        while not done.wait(1.0):
+            if time.time() - stage["t0"] > limit:
+                sys.stderr.write("bench.py preflight: rank %d STUCK for %.0f s in: %s (stages before it: %s)\n"
+                                 % (rank, time.time() - stage["t0"], stage["name"], "; ".join("%s %.1f s" % t for t in stage["log"])))
+                sys.stderr.flush()
+                os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
 
     def enter(name):
+        stage["log"].append((stage["name"], time.time() - stage["t0"]))
         stage["name"] = name
         stage["t0"] = time.time()
     n, dims = 64, [19, 4096, 4]                     # 64 rows x 4096 floats = 1 MB per peer; dW0 = 19 x 4096 floats = 311 KB
@@ -684,6 +693,7 @@ def first_contact_preflight(da, dist, torch, rank, world, dev, host_tx, tdev):
     done.set()
     res["ok"] = bool(flag.item())
     res["seconds"] = round(time.time() - t0, 2)
+    res["stage_seconds"] = {n_: round(t_, 3) for n_, t_ in stage["log"][1:]}
     res["transport"] = "host callbacks over gloo" if host_tx else "RCCL"
     if not res["ok"]:
         raise SystemExit("bench.py preflight FAILED on rank %d: exchanged ghost rows or the gradient sum are wrong (%r)" % (rank, res))

@@ -839,6 +839,13 @@ int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     // read-only counters of the K1s gates (device words that outlive the launches): timeouts = a sweep's workgroups were
     // not co-resident within the polling bound; ungated launches = launches that ran without gates while the context
     // backed off after a timeout (same results, unsynchronised rate)
+    if (key && value && !strcmp(key, "spmm_gates_rearm")) {   // (write-only action; reads as "is a back-off pending": launch number below a horizon)
+        uint32_t st[SWEEP_STAT_WORDS] = {0};
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
+        *value = (st[4] < st[1] || st[4] < st[3]) ? 1 : 0;
+        return DORY_OK;
+    }
     if (key && value && !strcmp(key, "spmm_xcd_mapping_ok")) { *value = c->xcd_mapping_ok ? 1 : 0; return DORY_OK; }   // read-only: dory_create's check
     if (key && value && !strcmp(key, "spmm_xcd_count")) { *value = c->xcd_count; return DORY_OK; }
     if (key && value && !strcmp(key, "spmm_xcd_policy")) { *value = c->xcd_policy; return DORY_OK; }                  // -1 undecided / not needed, 0 gated, 8 ungated
@@ -867,6 +874,7 @@ int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
     CHECK_CTX(c);
     if (key && !strcmp(key, "spmm_gates_rearm")) {   // write-only: end a K1s gate back-off now (both launch classes); the counters stay.
         // For a caller that has just changed what caused the timeouts (bench.py trying another spmm_sweep_reserve_cus).
+        if (c->capturing) return fail(c, DORY_ERR_ARG, "spmm_gates_rearm: not while an epoch graph is being recorded (it synchronises the stream)");
         HIPCK(c, hipStreamSynchronize(c->compute));
         const uint32_t zero = 0;
         HIPCK(c, hipMemcpy(c->sweep_stat + 1, &zero, sizeof(zero), hipMemcpyHostToDevice));

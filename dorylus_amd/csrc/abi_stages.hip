@@ -499,7 +499,9 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 HIPCK(c, launch_gatmh_backward_blocked_dst(c->N, K, D, z->ld, el->ld, Bbi, z->d, fgz->d, el->d, fgel->d,
                                                            er->d, m->d, den->d, dO->d, tt->d, der->d, c->partial, st4, lds4,
                                                            c->Gsrc > 0, c->compute,
-                                                           c->opt["gatmh_el_on_the_fly"] ? c->weights[fl]["a_l"].d : nullptr));
+                                                           // (el from the gathered row only where the forward formed its statistics that
+                                                           //  way too: its ELFLY form needs the fused statistics -- same rounding of alpha)
+                                                           (c->opt["gatmh_el_on_the_fly"] && c->opt["gatmh_fused_stats"]) ? c->weights[fl]["a_l"].d : nullptr));
             }
             if (phase == 1) return DORY_OK;
             if (phase == 0 && c->numNodes > 1) {   // ghost destinations of the out-edges: their dO and st rows

@@ -214,7 +214,10 @@ int main(int argc, char **argv) {
             bool ok = false;
             for (int tries = 0; tries < 600 && !ok; ++tries) {
                 struct stat sb;
-                if (stat(idFile.c_str(), &sb) == 0 && (unique_job || sb.st_mtim.tv_sec >= not_before)) {
+                // the job's nonce is what identifies the file; the age bound stays even then (a constant DORY_JOB_ID reused after a
+                // crashed job must not hand out that job's id: a day is far more than any launcher's skew, DORY_JOB_START tightens it)
+                const time_t bound = unique_job && !getenv("DORY_JOB_START") ? proc_start.tv_sec - 86400 : not_before;
+                if (stat(idFile.c_str(), &sb) == 0 && sb.st_mtim.tv_sec >= bound) {
                     if (FILE *f = fopen(idFile.c_str(), "rb")) {
                         char got[64];
                         ok = fread(id, 1, 128, f) == 128 && fread(got, 1, sizeof(got), f) == sizeof(got) &&
