@@ -202,3 +202,66 @@ def test_gat_mh_partitioned_epoch_vs_oracle(P, dims, heads):
     assert rel_err(gathered(1, "logits"), Hs[2]) < RTOL
     for c in ctxs:
         c.close()
+
+
+def test_gat_mh_sweep_underflow_rows_are_recomputed():
+    """The sweep forward shifts every row's scores by an UPPER BOUND (max over all sources of el + the row's er); a row whose
+    own neighbourhood lies far below it underflows (den -> 0).  Such rows must be detected and recomputed with their true
+    maximum (gatmh_forward_redo_kernel).  Attention vectors scaled until el spans several hundred: the bound is then
+    hundreds above most rows' own maxima."""
+    import dorylus_amd as da
+    import gat_mh_oracle as go
+    import partition_oracle as po
+    from helpers import rel_err
+    dims, heads, V, E = [40, 128, 41], [8, 1], 300, 4000
+    rng = np.random.default_rng(77)
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    params = []
+    for l in range(2):
+        zw = dims[l + 1] * (heads[l] if l == 1 else 1)
+        params.append([(rng.standard_normal((dims[l], zw)) / np.sqrt(dims[l])).astype(np.float32),
+                       (rng.standard_normal(zw) * (60.0 if l == 0 else 0.3)).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32)])
+    ctx = da.Context(0)
+    ctx.configure(da.GATMH, dims, V)
+    ctx.gatmh_heads(heads)
+    ctx.set_option("spmm_blk_nb", 8)          # the sweep kernels on this L2-sized graph
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    ctx.upload(0, "h", X)
+    ctx.labels_upload(labels)
+    for l, (W, al, ar) in enumerate(params):
+        ctx.weight_set(l, "w", W); ctx.weight_set(l, "a_l", al); ctx.weight_set(l, "a_r", ar)
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(1)
+    fws, Hs, loss, dlogits, grads = go.epoch(g, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
+    el, er = fws[0]["el"], fws[0]["er"]
+    assert el.max() - el.min() > 300                                  # the premise: scores span hundreds
+    bound = el.max(0)[None, :] + er
+    bound = np.where(bound > 0, bound, 0.2 * bound)                   # the sweep's shift
+    gap = bound - fws[0]["m"]                                         # how far above the row's own maximum it lies
+    under = (gap > 110).any(1)                                        # exp(-110) is far below the smallest fp32: den underflows
+    assert under.sum() >= 10
+    m_gpu = ctx.download(0, "m")
+    # recomputed rows carry their TRUE maximum (the online softmax of the redo kernel), the others the bound
+    assert np.abs(m_gpu[under] - fws[0]["m"][under]).max() < 1e-2 * np.abs(fws[0]["m"]).max()
+    safe = (gap < 60).all(1)
+    if safe.any():
+        assert np.abs(m_gpu[safe] - bound[safe]).max() < 1e-2 * np.abs(bound).max()
+    den = ctx.download(0, "den")
+    assert np.isfinite(den).all() and (den > 0).all()
+    lse = np.log(den.astype(np.float64)) + m_gpu
+    assert np.abs(lse - (np.log(fws[0]["den"]) + fws[0]["m"])).max() < 2e-3 * np.abs(fws[0]["m"]).max()
+    # scores of magnitude 300 carry fp32 rounding of ~3e-5 into the exponent: 2e-3 on what follows the softmax
+    for l in range(2):
+        assert rel_err(ctx.download(l, "o"), fws[l]["O"]) < 2e-3, (l, "o")
+        assert rel_err(ctx.download(l, "t"), grads[l]["t"]) < 5e-3, (l, "t")
+        # (with a nearly one-hot softmax d_er = sum alpha (dalpha - t) l' cancels to ~1e-17: compared on the scale of its terms, t)
+        assert np.abs(ctx.download(l, "der") - grads[l]["d_er"]).max() < 5e-3 * np.abs(grads[l]["t"]).max(), (l, "der")
+        assert rel_err(ctx.download(l, "dz"), grads[l]["dZ"]) < 5e-3, (l, "dz")
+    eng.close()
+    ctx.close()
