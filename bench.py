@@ -177,6 +177,14 @@ def git_blob_sha1(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
+def spmm_source_stamp():
+    """what a PMC traffic figure is stamped with: the sources of the aggregation kernels (K1 / K1s in spmm.hip, the sweep
+    skeleton they run on in sweep_core.hpp since round 5) -- one hash over both blobs"""
+    import hashlib
+    d = os.path.join(ROOT, "dorylus_amd", "csrc")
+    return hashlib.sha1((git_blob_sha1(os.path.join(d, "spmm.hip")) + git_blob_sha1(os.path.join(d, "sweep_core.hpp"))).encode()).hexdigest()
+
+
 def spmm_algorithmic_bytes(N, G, E, F):
     """compulsory bytes of one SpMM launch."""
     return E * 8 + 8 * (N + 1) + 4 * N + 4 * F * (N + G) + 4 * F * N
@@ -399,7 +407,7 @@ def main():
             ent = pm["spmm_variant_%d" % variant]
             # the counters were collected for ONE version of the kernel source: a later edit of spmm.hip without a new
             # collection must not leave a stale number in the record
-            have = git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip"))
+            have = spmm_source_stamp()
             if ent.get("spmm_hip_blob") in (None, have) or variant != 2:
                 traffic = ent["bytes_per_launch"]
                 traffic_src = ent.get("source")
@@ -751,7 +759,7 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
         traffic_, traffic_src_ = None, "no PMC pass on record for this configuration"
         try:     # HBM-side bytes per epoch from the separate --pmc FETCH_SIZE pass (profiles/), for the kernel source it was collected for
             ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(pmc_key or "", None)
-            if ent and ent.get("spmm_hip_blob") == git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip")):
+            if ent and ent.get("spmm_hip_blob") == spmm_source_stamp():
                 traffic_, traffic_src_ = ent["fetch_bytes_per_epoch"], ent["source"]
             elif ent:
                 traffic_src_ = "stale: collected for another spmm.hip -- re-run tools/collect_profiles.sh"

@@ -287,6 +287,26 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s);
 size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K);
 
+// tanh of the transform's epilogue (K2), of the stand-alone activation and of K3's backward -- one function for all three, so
+// that h and the 1 - tanh^2 of the backward pass are the same number.  libm's tanhf is ~40 vector instructions (40 M of the
+// 53.6 M of a 602->128 launch, round 4); this one is 13: an odd polynomial below 0.35 (Taylor through x^11: the next term is
+// 1.2e-8 relative there) and 1 - 2 / (1 + exp(2x)) above (v_exp_f32 + v_rcp_f32; at most ~3e-7 relative at the crossover,
+// where the subtraction costs most).  tests/test_gpu_parity.py::test_tanh_matches_libm: <= 1e-6 relative against the oracle.
+__device__ __forceinline__ float dory_tanh(float x) {
+#ifdef DORY_TANH_LIBM
+    return tanhf(x);
+#endif
+    const float ax = fabsf(x), x2 = x * x;
+    float p = fmaf(x2, 0.0088632355f, -0.021869488f);          // 1382/155925, -62/2835
+    p = fmaf(x2, p, 0.053968254f);                              // 17/315
+    p = fmaf(x2, p, -0.13333333f);                              // -2/15 ... signs alternate: tanh x = x - x^3/3 + 2x^5/15 - 17x^7/315 + 62x^9/2835 - 1382x^11/155925
+    p = fmaf(x2, p, 0.33333334f);
+    const float small = fmaf(-x * x2, p, x);                    // x - x^3 (1/3 - x^2 (2/15 - ...))
+    const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);   // exp(2|x|); inf for |x| > 44: 2/(1+inf) = 0
+    const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(1.f + t), x);
+    return ax < 0.35f ? small : big;
+}
+
 // K3/K4 elementwise + loss
 hipError_t launch_tanh_backward(uint64_t rows, uint32_t cols, const float *aTg, uint32_t lda,
                                 const float *z, uint32_t ldz, float *g, uint32_t ldg, hipStream_t s);

@@ -33,10 +33,10 @@ __global__ void tanh_backward_kernel(uint64_t rows, uint32_t cols, const float *
         const float4 zz = *reinterpret_cast<const float4 *>(z + r * ldz + c);
         float4 o;
         float t;
-        t = tanhf(zz.x); o.x = a.x * (1.f - t * t);
-        t = tanhf(zz.y); o.y = a.y * (1.f - t * t);
-        t = tanhf(zz.z); o.z = a.z * (1.f - t * t);
-        t = tanhf(zz.w); o.w = a.w * (1.f - t * t);
+        t = dory_tanh(zz.x); o.x = a.x * (1.f - t * t);
+        t = dory_tanh(zz.y); o.y = a.y * (1.f - t * t);
+        t = dory_tanh(zz.z); o.z = a.z * (1.f - t * t);
+        t = dory_tanh(zz.w); o.w = a.w * (1.f - t * t);
         // padding columns of aTg are zero, so padding of g stays zero
         *reinterpret_cast<float4 *>(g + r * ldg + c) = o;
     }
@@ -58,7 +58,7 @@ __global__ void tanh_forward_kernel(uint64_t rows, uint32_t cols, const float *z
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = i / cols;
         const uint32_t c = (uint32_t)(i % cols);
-        h[r * ldh + c] = tanhf(z[r * ldz + c]);
+        h[r * ldh + c] = dory_tanh(z[r * ldz + c]);
     }
 }
 hipError_t launch_tanh_forward(uint64_t rows, uint32_t cols, const float *z, uint32_t ldz, float *h, uint32_t ldh,

@@ -201,7 +201,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, floa
                     const float v = acc[a][b][r];
                     C[(size_t)row * g.ldc + col] = v;
                     if (!split && g.epilogue == EPI_TANH)
-                        g.C2[(size_t)row * g.ldc2 + col] = tanhf(v);
+                        g.C2[(size_t)row * g.ldc2 + col] = dory_tanh(v);
                 }
             }
         }
@@ -241,7 +241,7 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
         }
         for (; z < S; ++z) s += partial[(size_t)z * n + i];
         C[i] = s;
-        if (C2) C2[(i / ldc) * ldc2 + (i % ldc)] = tanhf(s);
+        if (C2) C2[(i / ldc) * ldc2 + (i % ldc)] = dory_tanh(s);
     }
 }
 

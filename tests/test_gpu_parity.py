@@ -1060,6 +1060,33 @@ def test_gat_epoch_partitions_vs_oracle(da, case, nb):
         c.close()
 
 
+def test_tanh_matches_libm(da):
+    """dory_tanh (csrc/ctx.hpp: odd polynomial below 0.35, 1 - 2 / (1 + exp 2x) above; 13 instructions for libm's ~40) in the
+    transform's epilogue: h = tanh(z) on the z the GPU itself holds, from 1e-6 to saturation, within 1e-6 relative of libm
+    (the oracle's tanhf, CPU_comm.cpp:265-274 `std::tanh`)."""
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph
+    V, dims = 4096, [64, 128, 8]
+    s, d = random_graph(3, V, 20000)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    X *= (10.0 ** rng.uniform(-6, 1.6, (V, 1))).astype(np.float32)     # rows of very different magnitude: z from 1e-6 to +-40
+    ctx = make_ctx(da, g, dims, V)
+    ctx.upload(0, "x", X)
+    ctx.weight_set(0, "w", (rng.standard_normal((dims[0], dims[1])) / 4).astype(np.float32))
+    ctx.weight_set(1, "w", np.zeros((dims[1], dims[2]), np.float32))
+    ctx.aggregate(0, da.FORWARD)
+    ctx.apply_vertex(0, da.FORWARD)
+    z, h = ctx.download(0, "z").astype(np.float64), ctx.download(0, "h").astype(np.float64)
+    ref = np.tanh(z)
+    nz = ref != 0
+    assert np.abs(z).max() > 20 and (np.abs(z) < 1e-3).mean() > 0.001 and ((np.abs(z) > 0.2) & (np.abs(z) < 0.6)).mean() > 0.01   # the premise: all three regimes are there
+    assert (np.abs(h - ref)[nz] / np.abs(ref[nz])).max() < 1e-6
+    assert np.array_equal(h[~nz], ref[~nz]) and np.abs(h).max() <= 1.0
+    ctx.close()
+
+
 def test_fill_uniform_matches_host_twin(da):
     import partition_oracle as po
     from helpers import make_ctx, random_graph, splitmix_uniform

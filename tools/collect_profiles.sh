@@ -34,6 +34,13 @@ python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_f -name '*.db'
 python "$R/bench.py" --graph community --no-cpu-baseline --no-alt > "$OUT/${TAG}_bench_community.json" 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_com_f -o p -- python "$R/bench.py" --graph community --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_com_f.log 2>&1
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_com_f -name '*.db' | head -1)" > "$OUT/${TAG}_community_pmc_fetch_size.txt" 2>&1
+# config 3 (8-head GAT, sweep forms): kernel summary + HBM-side bytes of its edge passes
+rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_gmh_k -o k -- python "$R/bench.py" --gnn gatmh --steps 5 --warmup 1 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_k.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_k -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_kernel_stats.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_gmh_f -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_f.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_f -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_fetch_size.txt" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_${TAG}_gmh_v -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_v.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_v -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_valu.txt" 2>&1
 cd "$R"
 python bench.py --gnn gat --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gat.json" 2>/dev/null
 python bench.py --gnn gatmh --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gatmh.json" 2>/dev/null

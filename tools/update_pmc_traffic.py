@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import git_blob_sha1  # noqa: E402
+from bench import spmm_source_stamp  # noqa: E402
 
 
 def counter_sum(path, counter, pattern):
@@ -36,20 +36,22 @@ def main():
         "fetch_size_kb_avg": round(fetch / launches, 1), "write_size_kb_avg": round(write / launches, 1),
         "bytes_per_launch": int((2 * fetch + write) / launches * 1024),
         "source": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt"],
-        "spmm_hip_blob": git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip")),
+        "spmm_hip_blob": spmm_source_stamp(),
         "note": "tools/collect_profiles.sh + tools/update_pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                 "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-alt`, summed over the sweep kernels of the epoch / 3 launches; "
                 "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported.  Round 2 (r02e): 10.445 GB",
     }
     # config 4 as one rank of 8 holds it (bench.py key amazon_rank0of8, K1 row gather): FETCH_SIZE of the epoch's five launches
-    amz = os.path.join(ROOT, "profiles", "r04_k1_amazon_rank_pmc_fetch_size.txt")
+    amz = os.path.join(ROOT, "profiles", f"{tag}_k1_amazon_rank_pmc_fetch_size.txt")
+    if not os.path.exists(amz):
+        amz = os.path.join(ROOT, "profiles", "r04_k1_amazon_rank_pmc_fetch_size.txt")
     if os.path.exists(amz):
         fetch_a, names_a = counter_sum(amz, "FETCH_SIZE", r"spmm_rows_kernel")
         pm["amazon_rank0of8"] = {
             "kernels": "spmm_rows_kernel<32,3> (F=300) + 4 x spmm_rows_kernel<16,1> (F=64): the five aggregations of one epoch",
             "fetch_size_kb_per_epoch": round(fetch_a, 1), "fetch_bytes_per_epoch": int(2 * fetch_a * 1024),
-            "source": ["profiles/r04_k1_amazon_rank_pmc_fetch_size.txt"],
-            "spmm_hip_blob": git_blob_sha1(os.path.join(ROOT, "dorylus_amd", "csrc", "spmm.hip")),
+            "source": ["profiles/" + os.path.basename(amz)],
+            "spmm_hip_blob": spmm_source_stamp(),
             "note": "rocprofv3 --pmc FETCH_SIZE pass of `bench.py --workload amazon --emulate 0/8 --steps 1 --warmup 0 --no-cpu-baseline "
                     "--no-alt` (tools/collect_profiles.sh); FETCH_SIZE doubled (gfx950); the write side (one N x ld row tensor per launch, "
                     "1.1 GB per epoch) was not collected",
