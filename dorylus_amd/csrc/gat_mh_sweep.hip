@@ -27,6 +27,9 @@
 
 namespace dory {
 
+#ifndef GATMH_SLACK
+#define GATMH_SLACK SWEEP_SLACK   // windows a workgroup may run ahead of its sweep's slowest: 0 / 1 / 2 = 20.5 / 18.0 / 18.4 ms per 8-head epoch (round 5)
+#endif
 #ifndef GATMH_SRC_BATCH
 #define GATMH_SRC_BATCH 4
 #endif
@@ -76,6 +79,7 @@ template <int GROUP, int HL, int R>
 struct GatFwdSweepOp {
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
     static constexpr int BATCH = GROUP == 16 ? 2 : SWEEP_U;    // (16-lane groups stage twice the entries per lane: the registers go there)
+    static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;                     // heads per slab of GROUP lanes
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
     // arguments
@@ -305,6 +309,7 @@ struct GatSrcSweepOp {
     // profiles/r05_gatmh_src_aux_batch_experiment.patch)
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
     static constexpr int BATCH = GROUP == 16 ? 2 : GATMH_SRC_BATCH;   // two gathers per entry: (rows, statistics)
+    static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
     // arguments

@@ -302,6 +302,7 @@ template <bool UNIT>
 struct SweepPlainOp {
     static constexpr bool PLAIN = true, UNIT_W = UNIT, PROLOGUE = false, AUX_BATCH = false;
     static constexpr int BATCH = SWEEP_U;     // gathers per batch
+    static constexpr int SLACK = SWEEP_SLACK; // windows a workgroup may run ahead of its sweep's slowest
     const float *row_scale;
     struct Row { float4 acc; };
     struct RowC {};

@@ -48,10 +48,11 @@ struct SweepArgs {
 // ---- the gate and the arrival, shared by the sweep kernels ------------------------------------------------------------
 // gate: step sb may start once every workgroup of the sweep has finished step sb - SWEEP_SLACK - 1 (for the first steps:
 // of the previous sweep of this XCD).  *lds_allowed = number of steps this workgroup may start.
+template <int SLACK = SWEEP_SLACK>
 __device__ __forceinline__ void sweep_gate(const SweepArgs &w, uint32_t seq, bool gated, uint32_t sb, uint32_t q, uint32_t nbs, uint32_t *dq,
                                            uint32_t cnt_q, uint32_t cnt_p, uint32_t *gates_off, uint32_t *lds_allowed,
                                            uint32_t *lds_lock, int lane) {
-    const int bb = (int)sb - SWEEP_SLACK - 1;
+    const int bb = (int)sb - SLACK - 1;
     const bool prev = bb < 0;
     const uint32_t *word = !prev ? dq + (size_t)bb * 32
                                  : (q > 0 && (int)nbs + bb >= 0 ? dq - (size_t)nbs * 32 + (size_t)((int)nbs + bb) * 32 : nullptr);
@@ -280,7 +281,7 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
 
     for (uint32_t b = w.b_lo; b < w.b_hi; ++b) {
         const uint32_t sb = b - w.b_lo;                      // step of this launch
-        sweep_gate(w, seq, gated, sb, q, nbs, dq, cnt_q, cnt_p, gates_off, &lds_allowed, &lds_lock, lane);
+        sweep_gate<OP::SLACK>(w, seq, gated, sb, q, nbs, dq, cnt_q, cnt_p, gates_off, &lds_allowed, &lds_lock, lane);
         uint32_t my_o_next = 0, o0, oR;
         uint64_t base;
         if constexpr (LOADER) {

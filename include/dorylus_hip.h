@@ -79,7 +79,14 @@ int dory_configure(dory_ctx *ctx, int gnn_type, uint32_t num_layers,
  * phases and ships "do" -> "bg_do" and "st" -> "bg_st" (the packed (er, m, 1/den, t) rows) of the out-edges' ghost
  * destinations in between -- itself over RCCL, or, with option "gatmh_bwd_phase" = 1 / 2, one phase per call so that
  * the caller can move those rows (dory_halo_pack_tensor / dory_halo_unpack_tensor); dory_halo_exchange(layer,
- * BACKWARD) is a no-op for this model.  Partitioned runs need the source-blocked kernels ("gatmh_blocked" = 1). */
+ * BACKWARD) is a no-op for this model.  Partitioned runs need the source-blocked kernels ("gatmh_blocked" = 1).
+ * Sweep forms (option "gatmh_sweep" = 1, default; round 5): where the K1s layouts apply and a head spans 2..16 lanes of a
+ * 16-byte-per-lane row slab, the forward runs on K1s's skeleton with a single-pass softmax against an upper-bound shift
+ * ("m" then holds that shift, "den" the matching denominator: alpha = exp(s - m) / den as before) and leaves two more
+ * tensors, "op" (the part of "o" that came over edges on LeakyReLU's positive branch) and "dpos" (their attention mass);
+ * the backward's destination side is then a row-wise kernel (t = <do, o>, der = 0.8 (<do, op> - t dpos)) and its source
+ * side a sweep over the out-edges' layout.  Other shapes, or "gatmh_sweep" = 0, keep the blocked kernels; the named
+ * tensors and the two-phase protocol are the same either way.  "gatmh_sweep_rows": rows per lane group of the layouts. */
 int dory_gatmh_heads(dory_ctx *ctx, const uint32_t *heads);
 
 /* Upload one partition's adjacency, exactly the arrays of Graph
@@ -218,7 +225,12 @@ int dory_timing_reset(dory_ctx *ctx);
  * context's next 16 K1s launches ran without gates -- same results, unsynchronised gather rate) and
  * "spmm_ungated_launches"; "epoch_graph_recorded".  dory_timing_get("spmm_gate_timeouts") returns the same pair
  * (launches = timeouts, total_ms = ungated launches).  Write-only key "spmm_gates_rearm": ends a gate back-off at once
- * (a caller that has just changed its cause, e.g. another "spmm_sweep_reserve_cus"); the counters stay. */
+ * (a caller that has just changed its cause, e.g. another "spmm_sweep_reserve_cus"); the counters stay (refused while an
+ * epoch graph is being recorded; read back: 1 while a back-off is pending).  K1s's placement assumption -- workgroups
+ * with equal id & 7 share an XCD, eight XCDs -- is checked once per context at dory_create with HW_REG_XCC_ID probes:
+ * read-only "spmm_xcd_mapping_ok", "spmm_xcd_count"; when it does not hold, the first repeatable K1s launch is timed with
+ * and without gates and the faster form kept ("spmm_xcd_policy": -1 nothing to decide, 0 gated, 8 ungated;
+ * "spmm_xcd_gated_us" / "spmm_xcd_ungated_us"); "spmm_xcd_assume_mismatch" = 1 forces that path (tests). */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
 /* Diagnostic (no reference counterpart): hold `workgroups` whole CUs for `usec` microseconds with a sleeping kernel on
