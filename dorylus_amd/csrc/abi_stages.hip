@@ -429,7 +429,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 HIPCK(c, launch_gatmh_elu_bwd(c->N, o->cols, dh->d, dh->ld, o->d, o->ld, dO->d, dO->ld, c->compute));
             }
         }
-        int rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
+        int rc = ensure_scratch(c, (size_t)2048 * z->cols * sizeof(float) + (size_t)c->N * K * 16 + 256);
         if (rc) return rc;
         // The sweep forms (gat_mh_sweep.hip).  Destination side: when this layer's forward ran on the skeleton it left the
         // positive-branch sums, and t / der / st come from a row-wise kernel -- no edge pass.  Source side: the sweep over the
@@ -482,7 +482,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                                                        c->weights[fl]["a_r"].d, del->d, dz->d, c->scratch, c->compute));
             }
             // (the attention gradients' column sums take the scratch buffer next: the sweep's sums are consumed by then)
-            if ((rc = ensure_scratch(c, (size_t)1024 * z->cols * sizeof(float) + 256))) return rc;
+            if ((rc = ensure_scratch(c, (size_t)2048 * z->cols * sizeof(float) + 256))) return rc;
             HIPCK(c, launch_gatmh_dattn(c->N, K, D, z->ld, el->ld, z->d, del->d, der->d, c->wgrads[fl]["a_l"].d,
                                         c->wgrads[fl]["a_r"].d, c->scratch, c->scratch_bytes, c->compute));
             return DORY_OK;
