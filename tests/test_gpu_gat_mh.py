@@ -109,6 +109,8 @@ def test_gat_mh_partitioned_epoch_vs_oracle(P, dims, heads):
     V, E = 240, 2600
     rng = np.random.default_rng(17)
     s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    d[:200] = 7                                                       # a hub destination and a hub source: rows the sweep layouts cut into
+    s[200:400] = 13                                                   # pieces, whose slots the ghost-block launch accumulates into
     parts = (rng.permutation(V) % P).astype(np.int64)                 # scattered ownership: many ghosts
     g_all = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
     gs = [po.preprocess(s, d, parts, r, P) for r in range(P)]
@@ -263,5 +265,57 @@ def test_gat_mh_sweep_underflow_rows_are_recomputed():
         # (with a nearly one-hot softmax d_er = sum alpha (dalpha - t) l' cancels to ~1e-17: compared on the scale of its terms, t)
         assert np.abs(ctx.download(l, "der") - grads[l]["d_er"]).max() < 5e-3 * np.abs(grads[l]["t"]).max(), (l, "der")
         assert rel_err(ctx.download(l, "dz"), grads[l]["dZ"]) < 5e-3, (l, "dz")
+    eng.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("dims,heads", [([40, 128, 41], [8, 1]), ([24, 32, 8], [4, 2])])
+def test_gat_mh_sweep_split_rows_and_pieces(dims, heads):
+    """Hub rows on both sides: a destination with 400 in-edges and a source with 400 out-edges (mean degree 15) are cut into
+    pieces by the sweep layouts (build_blocked_sweep: rows of more than twice the mean degree); their partial sums --
+    rows, positive-branch rows, denominators, (T, T+) -- land in slots and are combined in piece order
+    (gatmh_sweep_combine_kernel).  Whole epoch against the float64 oracle."""
+    import dorylus_amd as da
+    import gat_mh_oracle as go
+    import partition_oracle as po
+    from helpers import rel_err
+    V, E = 400, 6000
+    rng = np.random.default_rng(5 + len(dims) + dims[1])
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    d[:400] = 11                                            # hub destination
+    s[400:800] = 29                                         # hub source
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    assert np.diff(g["colPtr"].astype(np.int64)).max() >= 400 and np.diff(g["rowPtr"].astype(np.int64)).max() >= 400
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    params = []
+    for l in range(2):
+        zw = dims[l + 1] * (heads[l] if l == 1 else 1)
+        params.append([(rng.standard_normal((dims[l], zw)) / np.sqrt(dims[l])).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32)])
+    ctx = da.Context(0)
+    ctx.configure(da.GATMH, dims, V)
+    ctx.gatmh_heads(heads)
+    ctx.set_option("spmm_blk_nb", 8)
+    ctx.graph_upload(g)
+    ctx.preallocate()
+    ctx.upload(0, "h", X)
+    ctx.labels_upload(labels)
+    for l, (W, al, ar) in enumerate(params):
+        ctx.weight_set(l, "w", W); ctx.weight_set(l, "a_l", al); ctx.weight_set(l, "a_r", ar)
+    ctx.adam_config(0.01)
+    eng = da.NativeEngine(ctx)
+    eng.run(1)
+    fws, Hs, loss, dlogits, grads = go.epoch(g, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
+    for l in range(2):
+        assert rel_err(ctx.download(l, "o"), fws[l]["O"]) < RTOL, (l, "o")
+        assert rel_err(ctx.download(l, "t"), grads[l]["t"]) < 5e-4, (l, "t")
+        assert rel_err(ctx.download(l, "del"), grads[l]["d_el"]) < 5e-4, (l, "del")
+        assert rel_err(ctx.download(l, "der"), grads[l]["d_er"]) < 5e-4, (l, "der")
+        assert rel_err(ctx.download(l, "dz"), grads[l]["dZ"]) < 5e-4, (l, "dz")
+        assert rel_err(ctx.weight_grad_get(l, "w"), grads[l]["dW"]) < 5e-4, (l, "dW")
+        lse = np.log(ctx.download(l, "den").astype(np.float64)) + ctx.download(l, "m")
+        assert np.abs(lse - (np.log(fws[l]["den"]) + fws[l]["m"])).max() < 1e-4, (l, "log-sum-exp")
     eng.close()
     ctx.close()
