@@ -17,8 +17,8 @@ RTOL = 1e-4
     ([24, 256, 6], [4, 1], 170, 1200),       # 4 heads x 64: two 128-float slabs per row
     ([24, 256, 9], [32, 1], 140, 1000),      # 32 heads x 8
 ])
-@pytest.mark.parametrize("nb", [0, 8])    # 8: force the source-blocked forward on these L2-sized graphs
-def test_gat_mh_epoch_vs_oracle(dims, heads, V, E, nb):
+@pytest.mark.parametrize("nb,sweep", [(0, 1), (8, 1), (8, 0)])    # 8: force the L2-window kernels on these L2-sized graphs: the
+def test_gat_mh_epoch_vs_oracle(dims, heads, V, E, nb, sweep):       # sweep forms where the shape allows, or (sweep = 0) the blocked ones
     import dorylus_amd as da
     import gat_mh_oracle as go
     import partition_oracle as po
@@ -39,6 +39,7 @@ def test_gat_mh_epoch_vs_oracle(dims, heads, V, E, nb):
     ctx.configure(da.GATMH, dims, V)
     ctx.gatmh_heads(heads)
     ctx.set_option("spmm_blk_nb", nb)
+    ctx.set_option("gatmh_sweep", sweep)
     ctx.graph_upload(g)
     ctx.preallocate()
     ctx.upload(0, "h", X)
