@@ -164,7 +164,77 @@ static void run(int wgs_per_cu, int iters) {
     hipFree(d);
 }
 
-int main() {
+// round 5: K2's inner loop as a TM x TN register tile -- TM A-fragments and TN B-fragments out of LDS per k-step of 2,
+// TM * TN MFMAs -- at W workgroups of 4 waves per CU.  2 x 2 is today's tile (one fragment per MFMA); 2 x 4 reads 0.75.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void mfma_tile_loop(float *out, int iters) {
+    __shared__ float as[16 * 260], bs[16 * 132];
+    for (int i = threadIdx.x; i < 16 * 260; i += 256) as[i] = 1.f + i * 1e-6f;
+    for (int i = threadIdx.x; i < 16 * 132; i += 256) bs[i] = 1.f - i * 1e-6f;
+    __syncthreads();
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int lane = threadIdx.x & 63, fr = lane & 31, fk = lane >> 5;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = as[(kk + fk) * 260 + a * 32 + fr];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = bs[(kk + fk) * 132 + b * 32 + fr];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+template <int TM, int TN>
+static void run_tile(int wgs_per_cu, int iters) {
+    float *d;
+    hipMalloc(&d, 4096);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters / 8);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double flops = (double)grid * 4 * iters * 8 * TM * TN * (2.0 * 32 * 32 * 2);
+    int nw = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, mfma_tile_loop<TM, TN>, 256, 0);
+    printf("register tile %d x %d (%d LDS fragments per %d MFMAs), %d workgroups of 4 waves per CU requested (occupancy query: %d): %.3f ms  %.1f TFLOP/s  (%.3f of 157.3)\n",
+           TM, TN, TM + TN, TM * TN, wgs_per_cu, nw, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
+    hipFree(d);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) {   // round 5: register tiles only
+        for (int w : {1, 2, 4}) { run_tile<2, 2>(w, 4000); run_tile<2, 4>(w, 2000); run_tile<1, 4>(w, 4000); run_tile<4, 2>(w, 2000); }
+        return 0;
+    }
     run<4>(1, 20000);
     run<4>(2, 20000);
     run<4>(4, 20000);    // K2's occupancy (gemm_kernel_occ4) and accumulator count (2 x 2 tiles per wave)
