@@ -1,5 +1,5 @@
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (repo root)
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "oracle")); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
 import dorylus_amd as da, orc, partition_oracle as po
