@@ -30,6 +30,21 @@ namespace dory {
 #ifndef GATMH_SLACK
 #define GATMH_SLACK SWEEP_SLACK   // windows a workgroup may run ahead of its sweep's slowest: 0 / 1 / 2 = 20.5 / 18.0 / 18.4 ms per 8-head epoch (round 5)
 #endif
+#ifndef GATMH_SRC16_LOADER
+#define GATMH_SRC16_LOADER true
+#endif
+#ifndef GATMH_SRC16_BATCH
+#define GATMH_SRC16_BATCH 2
+#endif
+#ifndef GATMH_FWD16_ROWS
+#define GATMH_FWD16_ROWS 2
+#endif
+#ifndef GATMH_FWD16_BATCH
+#define GATMH_FWD16_BATCH SWEEP_U
+#endif
+#ifndef GATMH_SRC16_ROWS
+#define GATMH_SRC16_ROWS 2
+#endif
 #ifndef GATMH_SRC_BATCH
 #define GATMH_SRC_BATCH 4
 #endif
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256) void gatmh_elmax_kernel(uint32_t N, uint32_t G
 template <int GROUP, int HL, int R>
 struct GatFwdSweepOp {
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
-    static constexpr int BATCH = GROUP == 16 ? 2 : SWEEP_U;    // (16-lane groups stage twice the entries per lane: the registers go there)
+    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : SWEEP_U;
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;                     // heads per slab of GROUP lanes
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
@@ -308,7 +323,7 @@ struct GatSrcSweepOp {
     // (the destinations' statistics fetched once per batch through the LDS crossbar instead of once per entry: measured, no gain --
     // profiles/r05_gatmh_src_aux_batch_experiment.patch)
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
-    static constexpr int BATCH = GROUP == 16 ? 2 : GATMH_SRC_BATCH;   // two gathers per entry: (rows, statistics)
+    static constexpr int BATCH = GROUP == 16 ? GATMH_SRC16_BATCH : GATMH_SRC_BATCH;   // two gathers per entry (rows, statistics); 16-lane groups: four lane groups per gather instruction
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
@@ -463,9 +478,11 @@ int gatmh_sweep_hl(uint32_t K, uint32_t D, uint32_t ld) {
 // pass: 0 forward, 1 source side.
 int gatmh_sweep_rows(const BlockedAdj &S, int group, int HL, int pass) {
     const int r = (int)S.rows_per_group;
-    int cap;
-    if (pass == 0) cap = group == 32 ? 4 : (HL == 2 ? 2 : 4);       // forward: ten registers per row (sums, positive-branch sums, two denominators)
-    else cap = group == 32 && HL != 16 ? 4 : 2;                     // source side: ten per row and two gathers per entry in flight
+    // 16-lane launches (64-float layers) have twice the lane groups per workgroup: half the layout's rows per group walks the
+    // same rows per workgroup and step as the layout was dealt for.  Measured (round 5, Reddit-large, 8 heads, loader wave on):
+    // forward 2 / 4 rows = 2.50 / 2.77 ms, source side 2 / 4 / 6 rows = 2.91 / 3.01 / 3.50 ms
+    if (group == 16) return std::max(2, std::min(r / 2, pass == 0 ? GATMH_FWD16_ROWS : GATMH_SRC16_ROWS));
+    const int cap = pass == 0 ? 4 : (HL != 16 ? 4 : 2);   // ten registers per row; the source side keeps two gathers per entry in flight
     int R = std::min(r, cap);
     if (R == 3) R = 2;
     return R;
@@ -554,7 +571,7 @@ hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, u
     const dim3 bl(SWEEP_NT);
 #define GFS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_forward_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, er, a_l, c.keys, op, c.dacc, c.pos_slots, c.den_slots, K, D, ldk)
 #define GFS_R(HLV) do { if (R == 4) GFS(32, HLV, 4, true); else GFS(32, HLV, 2, true); } while (0)
-#define GFS_R16(HLV) do { if (R == 4) GFS(16, HLV, 4, false); else GFS(16, HLV, 2, false); } while (0)
+#define GFS_R16(HLV) do { if (R == 4) GFS(16, HLV, 4, true); else GFS(16, HLV, 2, true); } while (0)
     if (group == 32) {
         if (R > 4) return hipErrorInvalidValue;
         if (HL == 2) GFS_R(2); else if (HL == 4) GFS_R(4); else if (HL == 8) GFS_R(8); else GFS_R(16);
@@ -658,8 +675,10 @@ hipError_t launch_gatmh_src_sweep_part(uint32_t N, uint32_t G, uint32_t K, uint3
         if (HL == 2) GSS_R(2); else if (HL == 4) GSS_R(4); else if (HL == 8) GSS_R(8); else GSS_R(16);
 #undef GSS_R
     } else {
-        if (R != 2) return hipErrorInvalidValue;
-        if (HL == 2) GSS(16, 2, 2, false); else if (HL == 4) GSS(16, 4, 2, false); else if (HL == 8) GSS(16, 8, 2, false); else GSS(16, 16, 2, false);
+        if (R != 2 && R != 4 && R != 6) return hipErrorInvalidValue;
+#define GSS_R16(HLV) do { if (R == 4) GSS(16, HLV, 4, GATMH_SRC16_LOADER); else GSS(16, HLV, 2, GATMH_SRC16_LOADER); } while (0)
+        if (HL == 2) GSS_R16(2); else if (HL == 4) GSS_R16(4); else if (HL == 8) GSS_R16(8); else GSS_R16(16);
+#undef GSS_R16
     }
 #undef GSS
     return hipGetLastError();

@@ -125,10 +125,13 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
     constexpr int NGRP = SWEEP_NT / GROUP;
     constexpr int NW = SWEEP_NT / 64;
     constexpr int RW = NGRP * R;
-    constexpr int C = SWEEP_C, U = OP::BATCH, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
+    // staged (idx, val) pairs per lane group and pass.  With the loader wave a 16-lane launch (64 lane groups) gets 512-byte slots:
+    // three buffers of 64 x 1 KB would not fit the LDS, and its groups hold at most a few rows (tens of entries per step)
+    constexpr int C = (LOADER && GROUP == 16) ? SWEEP_C / 2 : SWEEP_C;
+    constexpr int U = OP::BATCH, CQ = C / (2 * GROUP), CE = C - 1;   // CQ 16-byte loads of two entries per lane; a pass holds CE entries (its first may be the odd one of a pair)
     constexpr int NBUF = LOADER ? 3 : 1;
     constexpr int OFFB = (RW + 1 + 63) / 64 * 64;           // LOADER: the block's base (lo, hi) sits behind the copied offsets
-    static_assert(!LOADER || (GROUP == 32 && C == 128), "the loader copies one 1 KB slot per lane group and instruction");
+    static_assert(!LOADER || (GROUP == 32 && C == 128) || (GROUP == 16 && C == 64), "the loader copies 1 KB per instruction: one slot of a 32-lane group, two of 16-lane groups");
     __shared__ uint2 stage[NBUF * NGRP][C];
     __shared__ uint32_t o_lds[LOADER ? 1 : NGRP][R + 2];
     __shared__ uint32_t offl[LOADER ? NBUF : 1][LOADER ? OFFB + 2 : 1];
@@ -250,10 +253,19 @@ __device__ __forceinline__ void sweep_run(const SpmmArgs &a, const BlockedAdj &B
         for (int j = 0; j < OFFB / 64; ++j)                  // the RW + 1 row offsets of the workgroup's positions
             if ((uint32_t)j * 64u + ln <= (uint32_t)RW)
                 __builtin_amdgcn_global_load_lds((gptr_t)(orow_b + min(pos0 + (uint32_t)j * 64u + ln, xend)), (lptr_t)&offl[LOADER ? buf : 0][LOADER ? j * 64 : 0], 4, 0, SWEEP_DMA_AUX);
+        if constexpr (GROUP == 32) {
 #pragma unroll
-        for (int gg = 0; gg < NGRP; ++gg) {                  // one 1 KB run of entries per lane group, from the even entry at or before its first
-            const uint64_t A0 = (base + (uint32_t)__builtin_amdgcn_readlane((int)gstart, gg)) & ~1ull;
-            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + lane), (lptr_t)&stage[buf * NGRP + gg][0], 16, 0, SWEEP_DMA_AUX);
+            for (int gg = 0; gg < NGRP; ++gg) {              // one 1 KB run of entries per lane group, from the even entry at or before its first
+                const uint64_t A0 = (base + (uint32_t)__builtin_amdgcn_readlane((int)gstart, gg)) & ~1ull;
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + lane), (lptr_t)&stage[buf * NGRP + gg][0], 16, 0, SWEEP_DMA_AUX);
+            }
+        } else {
+#pragma unroll
+            for (int gp = 0; gp < NGRP / 2; ++gp) {          // 16-lane groups: two 512-byte runs per instruction, the wave's halves on consecutive groups' slots
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)gstart, 2 * gp), s1 = (uint32_t)__builtin_amdgcn_readlane((int)gstart, 2 * gp + 1);
+                const uint64_t A0 = (base + (ln < 32u ? s0 : s1)) & ~1ull;
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const u4 *>(B.bent) + (A0 >> 1) + (ln & 31u)), (lptr_t)&stage[buf * NGRP + 2 * gp][0], 16, 0, SWEEP_DMA_AUX);
+            }
         }
     };
     auto uniform64 = [&](uint64_t v) -> uint64_t {

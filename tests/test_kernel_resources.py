@@ -49,7 +49,7 @@ def test_selectable_sweep_variants_do_not_spill():
         p = _tparams(name, "gatmh_forward_sweep_kernel")
         if p:   # GROUP, HL, R, LOADER -- the rule of gatmh_sweep_rows(pass 0)
             group, hl, r, _ = p
-            cap = 4 if group == 32 else (2 if hl == 2 else 4)
+            cap = 2 if group == 16 else 4
             if r <= cap:
                 seen["fwd"] += 1
                 if spill:
@@ -58,7 +58,7 @@ def test_selectable_sweep_variants_do_not_spill():
         p = _tparams(name, "gatmh_src_sweep_kernel")
         if p:   # the rule of gatmh_sweep_rows(pass 1)
             group, hl, r, _ = p
-            cap = 4 if (group == 32 and hl != 16) else 2
+            cap = 2 if group == 16 else (4 if hl != 16 else 2)
             if r <= cap:
                 seen["src"] += 1
                 if spill:
