@@ -12,10 +12,9 @@
 //   NT  grad = d  * W^T
 //   TN  dW   = ah^T * d        reduction over M: split-K over workgroups with a
 //                              deterministic second-stage sum (no atomics)
-// Tiling: 128 x BN block (BN = 128 or 64), BK = 16, 4 waves, each wave a
-// 64x64 (2x2 MFMA tiles) or 32x64 (1x2) register tile.  Both operands are staged
-// k-major in LDS (As[k][i], Bs[k][j]) so every fragment read is a conflict-free
-// ds_read_b32 of 32 consecutive floats per half-wave.
+// Tiling: 128 x BN block (BN = 128 or 64), 16-deep k-tiles, 4 waves, each wave a 64x64 (2x2 MFMA tiles) or 32x64 (1x2)
+// register tile; operand tiles travel global -> LDS by LDS-DMA into two stages (below).  Sum order per output element: k-tiles
+// in order, inside a k-tile the pairs (m, 8+m) for m = 0..7 -- fixed, whatever the grid.
 #include "ctx.hpp"
 
 namespace dory {
@@ -23,111 +22,83 @@ namespace dory {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-// k-tile depth is a template parameter of the kernels below; 16 everywhere: 34 KB of LDS per 128-wide workgroup -> 4
-// workgroups per CU (with 32 only 2 fit and the MFMA-bound 602->128 GEMMs run 7 % slower); the HBM-bound 64-wide
-// GEMMs of an Amazon-sized partition measured the same or a few per cent better with 16 than with 32
+// k-tile depth: 16 (two 16-KB stages per 128-wide workgroup -> 4 workgroups per CU)
 constexpr int BK_SPLIT = 32;   // granularity of the split-K plan
 
-// A (BK x BT) operand tile travels global -> registers -> LDS (k-major).  The two halves
-// are separate so that the loads of tile t+1 are in flight while tile t is multiplied.
-// kmajor source: elem(k,i) = p[k*ld+i]; otherwise elem(k,i) = p[i*ld+k] (transposing copy).
+// ---------------------------------------------------------------------------------------------------------------------
+// The body (round 5; the register-staged form it replaces -- bounds-checked loads in branches, a transposing pass of
+// ds_write_b32, one fragment register set -- measured 372 / 332 us for the 602->128 NN / TN launches inside the Reddit epoch,
+// this one 348 / 303 us; profiles/r05_gemm_dma_ab.txt).  Both operand tiles travel global -> LDS by `buffer_load_dwordx4 ... lds` (1 KB per wave instruction, no
+// VGPRs, no ds_write), out-of-range rows / k read zeros through the buffer resource (no branches), and the k-tile's fragments
+// are all read before its 8 x TM x TN MFMAs.  LDS images (the DMA writes lane-linear, so any swizzle is on the SOURCE side):
+//   k-major source  elem(k,i) = p[k*ld+i]  ->  image[k][i] as it lies; fragment = 8 ds_read_b32 (rows 8*fk+m, 32 consecutive i)
+//   row-major source elem(k,i) = p[i*ld+k] ->  image[i][16 k] with the row's four 16-byte quads XOR-ed by (i>>2)&3; fragment =
+//                                              two ds_read_b128 (quads 2*fk, 2*fk+1): conflict-free in ds_read_b128's lane groups
+// MFMA m of a k-tile multiplies k = m (lanes 0-31) and k = 8+m (lanes 32-63) -- the same pairing for both image kinds.
 template <int BT, bool KMAJOR, int BK>
-struct TileRegs {
-    static constexpr int N4 = BT * BK / 4 / 256;   // float4 per thread
-    float4 v[N4];
-};
+struct DmaTile {
+    static_assert(BK == 16, "image geometry is written for 16-deep k-tiles");
+    static constexpr int PIECES = BT * BK * 4 / 1024 / 4;   // 1-KB pieces per wave (4 waves)
+    uint32_t voff;       // this lane's byte offset inside a piece's source (constant over the k-loop)
+    uint32_t pstride;    // byte distance between this wave's consecutive pieces
+    uint32_t step;       // bytes the source advances per k-tile
+    const char *base;    // source of the current k-tile
+    int64_t left;        // bytes readable from base on (rows / k beyond it read zeros)
 
-template <int BT, bool KMAJOR, int BK>
-__device__ __forceinline__ void tile_load(TileRegs<BT, KMAJOR, BK> &r, const float *__restrict__ p, uint32_t ld,
-                                          uint32_t ext, uint32_t Kend, uint32_t i0, uint32_t k0) {
-    const int t = threadIdx.x;
-    if constexpr (KMAJOR) {
-        constexpr int VPR = BT / 4;          // float4 per k-row
-        constexpr int KPI = 256 / VPR;       // k rows per iteration
-        const int i4 = (t % VPR) * 4;
-#pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
-            const uint32_t k = k0 + t / VPR + it * KPI;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < Kend) {
-                const float *src = p + (size_t)k * ld + i0 + i4;
-                if (i0 + i4 + 3 < ext) {
-                    v = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    if (i0 + i4 + 0 < ext) v.x = src[0];
-                    if (i0 + i4 + 1 < ext) v.y = src[1];
-                    if (i0 + i4 + 2 < ext) v.z = src[2];
-                }
-            }
-            r.v[it] = v;
-        }
-    } else {
-        constexpr int LPR = BK / 4;          // lanes per row (8)
-        constexpr int RPI = 256 / LPR;       // rows per iteration (32)
-        const int kq = (t % LPR) * 4;
-#pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
-            const uint32_t i = i0 + t / LPR + it * RPI;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < ext) {
-                const float *src = p + (size_t)i * ld + k0 + kq;
-                if (k0 + kq + 3 < Kend) {
-                    v = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    if (k0 + kq + 0 < Kend) v.x = src[0];
-                    if (k0 + kq + 1 < Kend) v.y = src[1];
-                    if (k0 + kq + 2 < Kend) v.z = src[2];
-                }
-            }
-            r.v[it] = v;
+    __device__ __forceinline__ void init(const float *p, uint32_t ld, uint32_t ext, uint32_t i0, uint32_t k0, uint32_t kend) {
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint64_t row_b = (uint64_t)ld * 4u;
+        if constexpr (KMAJOR) {   // a piece = 1024 / (BT*4) whole k-rows of the tile
+            constexpr uint32_t KPP = 256 / BT, LPR = BT / 4;
+            base = reinterpret_cast<const char *>(p) + (uint64_t)k0 * row_b + (uint64_t)i0 * 4u;
+            voff = (wave * PIECES * KPP + lane / LPR) * (uint32_t)row_b + (lane % LPR) * 16u;
+            pstride = KPP * (uint32_t)row_b;
+            step = BK * (uint32_t)row_b;
+            left = (int64_t)(kend - k0) * (int64_t)row_b - (int64_t)i0 * 4;
+        } else {                  // a piece = 16 rows x 64 bytes; quads swizzled by the row
+            const uint32_t r = wave * PIECES * 16u + (lane >> 2);
+            const uint32_t q = (lane & 3u) ^ ((r >> 2) & 3u);
+            base = reinterpret_cast<const char *>(p) + (uint64_t)i0 * row_b + (uint64_t)k0 * 4u;
+            voff = r * (uint32_t)row_b + q * 16u;
+            pstride = 16u * (uint32_t)row_b;
+            step = BK * 4u;
+            left = (int64_t)(ext - i0) * (int64_t)row_b - (int64_t)k0 * 4;
         }
     }
-}
+    // issue this wave's pieces of the current k-tile into `img` (BT*BK floats), then move on to the next k-tile
+    __device__ __forceinline__ void issue(float *img) {
+        const uint32_t wave = threadIdx.x >> 6;
+        const uint32_t n = left <= 0 ? 0u : (left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)left);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, n, 0x00020000);
+        typedef __attribute__((address_space(3))) void *lptr_t;
+#pragma unroll
+        for (int pc = 0; pc < PIECES; ++pc)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(img + (wave * PIECES + pc) * 256), 16, voff, pc * pstride, 0, 0);
+        base += step;
+        left -= step;
+    }
+};
 
-template <int BT, bool KMAJOR, int LLD, int BK>
-__device__ __forceinline__ void tile_store(float *lds, const TileRegs<BT, KMAJOR, BK> &r) {
-    const int t = threadIdx.x;
+// the eight k-values of a k-tile this lane feeds to the MFMAs, for the 32-row block `blk` of an image
+template <int BT, bool KMAJOR>
+__device__ __forceinline__ void dma_frag(float (&f)[8], const float *img, int blk, int fr, int fk) {
     if constexpr (KMAJOR) {
-        constexpr int VPR = BT / 4;
-        constexpr int KPI = 256 / VPR;
-        const int i4 = (t % VPR) * 4;
 #pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it)
-            *reinterpret_cast<float4 *>(lds + (t / VPR + it * KPI) * LLD + i4) = r.v[it];
+        for (int m = 0; m < 8; ++m) f[m] = img[(8 * fk + m) * BT + blk * 32 + fr];
     } else {
-        constexpr int LPR = BK / 4;
-        constexpr int RPI = 256 / LPR;
-        const int kq = (t % LPR) * 4;
-#pragma unroll
-        for (int it = 0; it < TileRegs<BT, KMAJOR, BK>::N4; ++it) {
-            const int rr = t / LPR + it * RPI;
-            lds[(kq + 0) * LLD + rr] = r.v[it].x;
-            lds[(kq + 1) * LLD + rr] = r.v[it].y;
-            lds[(kq + 2) * LLD + rr] = r.v[it].z;
-            lds[(kq + 3) * LLD + rr] = r.v[it].w;
-        }
+        const int r = blk * 32 + fr;
+        const int sw = (r >> 2) & 3;
+        const float4 lo = *reinterpret_cast<const float4 *>(img + r * 16 + ((2 * fk) ^ sw) * 4);
+        const float4 hi = *reinterpret_cast<const float4 *>(img + r * 16 + ((2 * fk + 1) ^ sw) * 4);
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+        f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
     }
 }
-
-// LDS geometry of one (BN, operand layouts, BK) instantiation.  Row-major operands are transposed on their way into
-// LDS: BK/4 k-lanes x 32/(BK/4) rows per 32-lane group write (kq + c) * LD + rr, so the row pitch is chosen to keep
-// the 32 banks distinct: LD = 2 (mod 32) for BK = 16 (kq in {0,4,8,12}, rr in 0..7), LD = 1 (mod 32) for BK = 32.
-template <int BN, bool A_KMAJOR, bool B_KMAJOR, int BK>
-struct GemmLds {
-    static constexpr int TPAD = BK == 16 ? 2 : 1;
-    static constexpr int LDA_S = A_KMAJOR ? BM + 4 : BM + TPAD;
-    static constexpr int LDB_S = B_KMAJOR ? BN + 4 : BN + TPAD;
-    static constexpr int A_SZ = (BK * LDA_S + 3) & ~3;
-    static constexpr int B_SZ = (BK * LDB_S + 3) & ~3;
-    static constexpr int FLOATS = 2 * (A_SZ + B_SZ);   // two buffers per operand: tile t+1 is written while nobody reads it
-};
 
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
-__device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, float *partial, float *smem) {
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs &g, uint32_t klen, float *partial, float *smem) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    using Lds = GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>;
-    constexpr int LDA_S = Lds::LDA_S, LDB_S = Lds::LDB_S, A_SZ = Lds::A_SZ, B_SZ = Lds::B_SZ;
-
+    constexpr int A_SZ = BM * BK, B_SZ = BN * BK, STAGE = A_SZ + B_SZ;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -135,6 +106,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, floa
     const uint32_t j0 = blockIdx.y * BN;
     const uint32_t kbeg = blockIdx.z * klen;
     const uint32_t kend = min(g.K, kbeg + klen);
+    const int fr = lane & 31, fk = lane >> 5;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -144,49 +116,50 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int fr = lane & 31;   // row/col inside the 32-wide fragment
-    const int fk = lane >> 5;   // k offset inside the 2-deep MFMA
-    TileRegs<BM, A_KMAJOR, BK> ra;
-    TileRegs<BN, B_KMAJOR, BK> rb;
-    int cur = 0;
-    if (kbeg < kend) {
-        tile_load<BM, A_KMAJOR, BK>(ra, g.A, g.lda, g.M, kend, i0, kbeg);
-        tile_load<BN, B_KMAJOR, BK>(rb, g.B, g.ldb, g.N, kend, j0, kbeg);
-        tile_store<BM, A_KMAJOR, LDA_S, BK>(smem, ra);
-        tile_store<BN, B_KMAJOR, LDB_S, BK>(smem + A_SZ, rb);
-    }
-    __syncthreads();
-    for (uint32_t k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) {  // next tile: global -> registers, in flight during the MFMAs below
-            tile_load<BM, A_KMAJOR, BK>(ra, g.A, g.lda, g.M, kend, i0, k0 + BK);
-            tile_load<BN, B_KMAJOR, BK>(rb, g.B, g.ldb, g.N, kend, j0, k0 + BK);
-        }
-        const float *As = smem + cur * (A_SZ + B_SZ);
+    DmaTile<BM, A_KMAJOR, BK> ta;
+    DmaTile<BN, B_KMAJOR, BK> tb;
+    ta.init(g.A, g.lda, g.M, i0, kbeg, kend);
+    tb.init(g.B, g.ldb, g.N, j0, kbeg, kend);
+    const uint32_t T = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    if (T) { ta.issue(smem); tb.issue(smem + A_SZ); }
+    for (uint32_t t = 0; t < T; ++t) {
+        // this wave's pieces of tile t have landed; past the barrier everybody's have, and nobody still reads the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float *As = smem + (t & 1) * STAGE;
         const float *Bs = As + A_SZ;
+        float af[TM][8], bf[TN][8];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int a = 0; a < TM; ++a) dma_frag<BM, A_KMAJOR>(af[a], As, wm * TM + a, fr, fk);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = As[(kk + fk) * LDA_S + (wm * TM + a) * 32 + fr];
+        for (int b = 0; b < TN; ++b) dma_frag<BN, B_KMAJOR>(bf[b], Bs, wn * TN + b, fr, fk);
+        // the next tile's DMA goes out AFTER this tile's fragment reads: hipcc orders any LDS read behind a pending LDS-DMA
+        // with vmcnt(0), which would put the DMA's latency in front of the MFMAs instead of under them
+        if (t + 1 < T) {
+            float *nx = smem + ((t + 1) & 1) * STAGE;
+            ta.issue(nx);
+            tb.issue(nx + A_SZ);
+        }
+        if (t + 1 == T && (kend & (BK - 1))) {   // a row-major operand's last quad may hold k >= K: whatever lies there must not count
+            const uint32_t kb = kbeg + t * BK + 8 * fk;
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = Bs[(kk + fk) * LDB_S + (wn * TN + b) * 32 + fr];
+            for (int m = 0; m < 8; ++m)
+                if (kb + m >= kend) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) af[a][m] = 0.f;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bf[b][m] = 0.f;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        if (more) {
-            float *An = smem + (cur ^ 1) * (A_SZ + B_SZ);
-            tile_store<BM, A_KMAJOR, LDA_S, BK>(An, ra);
-            tile_store<BN, B_KMAJOR, LDB_S, BK>(An + A_SZ, rb);
-        }
-        __syncthreads();
-        cur ^= 1;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
     }
 
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool split = gridDim.z > 1;
     float *C = split ? partial + (size_t)blockIdx.z * g.M * g.ldc : g.C;
 #pragma unroll
@@ -207,18 +180,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, uint32_t klen, floa
         }
 }
 
-// 64-wide tiles: the registers fit six waves per SIMD without a hint
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, uint32_t klen, float *partial) {
-    __shared__ __attribute__((aligned(16))) float smem[GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>::FLOATS];
-    gemm_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs g, uint32_t klen, float *partial) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BK];
+    gemm_dma_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
 }
-// 128-wide tiles with BK = 16: 34 KB of LDS -> four workgroups per CU if the kernel stays within 128 registers
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel_occ4(GemmArgs g, uint32_t klen,
-                                                                                                 float *partial) {
-    __shared__ __attribute__((aligned(16))) float smem[GemmLds<BN, A_KMAJOR, B_KMAJOR, BK>::FLOATS];
-    gemm_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dma_kernel_occ4(GemmArgs g, uint32_t klen,
+                                                                                                     float *partial) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BK];
+    gemm_dma_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
 }
 
 // second stage of split-K: C = sum_z partial[z] in z order (deterministic); eight
@@ -282,12 +253,12 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
     S = (g.K + klen - 1) / klen;
     dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, S);
     dim3 block(256);
-#define GEMM_LAUNCH(AK, BKM)                                                                                              \
-    do {                                                                                                                  \
-        if constexpr (BN == 128)                                                                                          \
-            hipLaunchKernelGGL((gemm_kernel_occ4<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch); \
-        else                                                                                                              \
-            hipLaunchKernelGGL((gemm_kernel<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch);      \
+#define GEMM_LAUNCH(AK, BKM)                                                                                                  \
+    do {                                                                                                                      \
+        if constexpr (BN == 128)                                                                                              \
+            hipLaunchKernelGGL((gemm_dma_kernel_occ4<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((gemm_dma_kernel<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch);      \
     } while (0)
     if (!g.ta && !g.tb) GEMM_LAUNCH(false, true);
     else if (!g.ta && g.tb) GEMM_LAUNCH(false, false);
@@ -309,6 +280,9 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
 
 hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, hipStream_t s) {
     if (g.M == 0 || g.N == 0) return hipSuccess;
+    // the DMA moves 16-byte pieces: rows must start on 16-byte boundaries (every tensor of the table does: ld is padded to 32 floats)
+    if ((g.lda & 3u) || (g.ldb & 3u) || (reinterpret_cast<uintptr_t>(g.A) & 15u) || (reinterpret_cast<uintptr_t>(g.B) & 15u))
+        return hipErrorInvalidValue;
     if (g.N > 64) return launch_bn<128, 2, 2, 2, 2, 16>(g, scratch, scratch_bytes, s);
     return launch_bn<64, 4, 1, 1, 2, 16>(g, scratch, scratch_bytes, s);
 }

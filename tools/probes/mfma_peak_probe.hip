@@ -167,10 +167,12 @@ static void run(int wgs_per_cu, int iters) {
 // round 5: K2's inner loop as a TM x TN register tile -- TM A-fragments and TN B-fragments out of LDS per k-step of 2,
 // TM * TN MFMAs -- at W workgroups of 4 waves per CU.  2 x 2 is today's tile (one fragment per MFMA); 2 x 4 reads 0.75.
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void mfma_tile_loop(float *out, int iters) {
+__global__ __launch_bounds__(256) void mfma_tile_loop(float *out, int iters, int rnd) {
     __shared__ float as[16 * 260], bs[16 * 132];
-    for (int i = threadIdx.x; i < 16 * 260; i += 256) as[i] = 1.f + i * 1e-6f;
-    for (int i = threadIdx.x; i < 16 * 132; i += 256) bs[i] = 1.f - i * 1e-6f;
+    // rnd: operands with random mantissas and signs (what a real GEMM multiplies) instead of ~1.0 -- the data a power-limited
+    // clock responds to
+    for (int i = threadIdx.x; i < 16 * 260; i += 256) as[i] = rnd ? ((int)((i * 2654435761u + blockIdx.x * 40503u) >> 8) - 8388608) * 1.1920929e-7f : 1.f + i * 1e-6f;
+    for (int i = threadIdx.x; i < 16 * 132; i += 256) bs[i] = rnd ? ((int)((i * 2246822519u + blockIdx.x * 9973u) >> 8) - 8388608) * 1.1920929e-7f : 1.f - i * 1e-6f;
     __syncthreads();
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -204,18 +206,18 @@ __global__ __launch_bounds__(256) void mfma_tile_loop(float *out, int iters) {
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 template <int TM, int TN>
-static void run_tile(int wgs_per_cu, int iters) {
+static void run_tile(int wgs_per_cu, int iters, int rnd = 0) {
     float *d;
     hipMalloc(&d, 4096);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = 256 * wgs_per_cu;
-    hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters / 8);
+    hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters / 8, rnd);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters);
+        hipLaunchKernelGGL((mfma_tile_loop<TM, TN>), dim3(grid), dim3(256), 0, 0, d, iters, rnd);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -225,12 +227,16 @@ static void run_tile(int wgs_per_cu, int iters) {
     const double flops = (double)grid * 4 * iters * 8 * TM * TN * (2.0 * 32 * 32 * 2);
     int nw = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, mfma_tile_loop<TM, TN>, 256, 0);
-    printf("register tile %d x %d (%d LDS fragments per %d MFMAs), %d workgroups of 4 waves per CU requested (occupancy query: %d): %.3f ms  %.1f TFLOP/s  (%.3f of 157.3)\n",
-           TM, TN, TM + TN, TM * TN, wgs_per_cu, nw, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
+    printf("%sregister tile %d x %d (%d LDS fragments per %d MFMAs), %d workgroups of 4 waves per CU requested (occupancy query: %d): %.3f ms  %.1f TFLOP/s  (%.3f of 157.3)\n",
+           rnd ? "[random operands] " : "", TM, TN, TM + TN, TM * TN, wgs_per_cu, nw, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
     hipFree(d);
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'r') {   // round 5: does the operand data move the sustained rate (power-managed clock)?
+        for (int rnd : {0, 1, 0, 1}) { run_tile<2, 4>(4, 4000, rnd); run_tile<1, 4>(4, 8000, rnd); }
+        return 0;
+    }
     if (argc > 1) {   // round 5: register tiles only
         for (int w : {1, 2, 4}) { run_tile<2, 2>(w, 4000); run_tile<2, 4>(w, 2000); run_tile<1, 4>(w, 4000); run_tile<4, 2>(w, 2000); }
         return 0;
