@@ -569,7 +569,8 @@ hipError_t build_blocked_sweep(const uint64_t *ptr, const uint32_t *idx, const f
 // rows per lane group: the choice that leaves the fewest idle workgroup slots in the last sweep of a slab;
 // force_r (option spmm_sweep_rows of the context; tests, experiments): 0 = pick by fill
 int sweep_pick_r(uint32_t N, int group, uint32_t G, int force_r, int max_r) {
-    if (force_r == 2 || force_r == 4 || force_r == 6 || force_r == 8 || (force_r == 10 && group == 32 && max_r >= 10))
+    if (force_r == 2 || force_r == 4 || force_r == 6 || force_r == 8 || (force_r == 10 && group == 32 && max_r >= 10) ||
+        ((force_r == 3 || force_r == 5) && group == 16))
         return force_r;
     const uint32_t rpx = (N + 7) / 8;
     int best = 8;
@@ -600,7 +601,10 @@ static int sweep_rows_for(const BlockedAdj &B, int group, uint32_t G, int force_
     if (force_r && forced == force_r) return forced;
     // (16-lane groups stage twice the entries per lane: eight rows spill two registers into the chain LDS -> gathers -> sums;
     // a spilling variant is not launched unless an option forces it -- tests/test_kernel_resources.py)
-    if (B.rows_per_group && group == 16) return std::min<int>((int)B.rows_per_group, 6);
+    // 16-lane launches (64-float rows) have twice the lane groups per workgroup: half the layout's rows per group walks the
+    // rows per workgroup and step the layout was dealt for, and leaves registers for the loader wave (round 5: the 64-float
+    // aggregations of the GAT prototype 2.00 -> see DESIGN; 6 rows without the loader was the round-4 form)
+    if (B.rows_per_group && group == 16) return std::max<int>(2, (int)B.rows_per_group / 2);
     if (B.rows_per_group && group == 32) return (int)B.rows_per_group;
     return sweep_pick_r(B.npos, group, G, 0, 10);
 }
@@ -649,7 +653,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     // rows in pairs (one stream of entries per two rows) pay on launches of several slabs (five slabs, F=602: 13.8 ->
     // 13.3 ms; four: 11.0 -> 10.8; three: 8.16 -> 8.1), not on one or two (F=128: 2.70 -> 2.78; F=256: 5.43 -> 5.46);
     // ctl.pair (option spmm_sweep_pair): -1 = that rule, 0 / 1 = forced (experiments)
-    const bool pair = ctl.pair < 0 ? slabs >= 3 : ctl.pair != 0;
+    const bool pair = (R & 1) ? false : (ctl.pair < 0 ? slabs >= 3 : ctl.pair != 0);   // (odd R: 16-lane launches on a 6- or 10-row layout)
 #define SWEEP_LAUNCH_L(GRP, RR, LD)                                                                                    \
     do {                                                                                                               \
         if (unit) { if (pair) hipLaunchKernelGGL((spmm_sweep_kernel<GRP, RR, true, true, LD>), gr, bl, 0, s, a, B, row_scale, w);   \
@@ -659,7 +663,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
     } while (0)
 #define SWEEP_LAUNCH(GRP, RR)                                                                                          \
     do {                                                                                                               \
-        if (GRP == 32 && ctl.loader) SWEEP_LAUNCH_L(32, RR, true); else SWEEP_LAUNCH_L(GRP, RR, false);                \
+        if (ctl.loader) SWEEP_LAUNCH_L(GRP, RR, true); else SWEEP_LAUNCH_L(GRP, RR, false);                            \
     } while (0)
 #define SWEEP_LAUNCH_R(GRP)                                                                                            \
     do {                                                                                                               \
@@ -667,7 +671,7 @@ hipError_t launch_spmm_sweep(const SpmmArgs &a, const BlockedAdj &B, int group, 
         else SWEEP_LAUNCH(GRP, 2);                                                                                     \
     } while (0)
     if (group == 32) { if (R == 10) SWEEP_LAUNCH(32, 10); else SWEEP_LAUNCH_R(32); }
-    else SWEEP_LAUNCH_R(16);
+    else { if (R == 5) SWEEP_LAUNCH(16, 5); else if (R == 3) SWEEP_LAUNCH(16, 3); else SWEEP_LAUNCH_R(16); }
 #undef SWEEP_LAUNCH_R
 #undef SWEEP_LAUNCH
 #undef SWEEP_LAUNCH_L
