@@ -41,6 +41,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_gmh_f -o p -- pyth
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_f -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_fetch_size.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_${TAG}_gmh_v -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_v.log 2>&1
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_v -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_valu.txt" 2>&1
+# the reference's single-head GAT prototype (rows a-6 / a-8): kernel summary of its epoch
+rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_gat_k -o k -- python "$R/bench.py" --gnn gat --steps 5 --warmup 1 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gat_k.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gat_k -name '*.db' | head -1)" > "$OUT/${TAG}_gat_kernel_stats.txt" 2>&1
 cd "$R"
 python bench.py --gnn gat --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gat.json" 2>/dev/null
 python bench.py --gnn gatmh --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_gatmh.json" 2>/dev/null
