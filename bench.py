@@ -442,7 +442,7 @@ def main():
     if gemm_ms > 0 and gemm_flops:
         tf = gemm_flops * args.steps / (gemm_ms * 1e-3) / 1e12
         roofline_gemm = {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.0, "unit": "TFLOP/s",
-                         "frac": round(tf / 157.0, 4), "kernel": "gemm_kernel<BN,...> fp32 MFMA 32x32x2 (+ split-K reduce)",
+                         "frac": round(tf / 157.0, 4), "kernel": "gemm_dma_kernel<BN,...> fp32 MFMA 32x32x2, operand tiles by LDS-DMA (+ split-K reduce)",
                          "flops_per_epoch": int(gemm_flops), "ms_per_epoch": round(gemm_ms / args.steps, 4)}
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on this box's cores ----------
