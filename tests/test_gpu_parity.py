@@ -1193,3 +1193,60 @@ def test_sweep_variant_random_shapes(da):
         c = da.Context(0)
         c.set_option("spmm_sweep_rows", 0)
         c.close()
+
+
+def _poison_padding(ctx, layer, name):
+    """NaN into the padding columns [cols, ld) of a device tensor, through its dory_tensor_info pointer"""
+    import ctypes as C
+    rows, cols, ld, p = ctx.info(layer, name)
+    if ld == cols or rows == 0:
+        return 0
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy2D.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    pad = np.full((rows, ld - cols), np.nan, np.float32)
+    ctx.sync()
+    rc = hip.hipMemcpy2D(C.c_void_p(p + cols * 4), ld * 4, pad.ctypes.data_as(C.c_void_p), (ld - cols) * 4, (ld - cols) * 4, rows, 1)
+    assert rc == 0
+    return ld - cols
+
+
+def test_gemm_does_not_read_operand_padding(da):
+    """K2's operand tiles come in 16-byte pieces of 16-deep k-tiles, so the last k-tile of a row-major operand covers columns
+    past K (602 -> 608, 24 -> 32, 12 -> 16): whatever lies there must not reach the product.  The tensors' padding is poisoned
+    with NaN right before every transform (NN with the tanh epilogue, TN split-K, NT) and the results are compared with the
+    oracle's -- a missing mask or a wrong out-of-range bound shows up as NaN, not as a 1e-7 difference."""
+    import orc
+    import partition_oracle as po
+    from helpers import assert_parity, make_ctx
+    V, dims = 777, [50, 24, 12, 7]
+    ids = np.arange(V)
+    g = po.preprocess(ids, ids, np.zeros(V, np.int64), 0, 1)     # one self edge per vertex: the graph does not matter here
+    rng = np.random.default_rng(77)
+    ctx = make_ctx(da, g, dims, V)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    for l in range(3):
+        ctx.weight_set(l, "w", Ws[l])
+    ah = [rng.uniform(-1, 1, (V, dims[l])).astype(np.float32) for l in range(3)]
+    # hidden layers, forward: z = ah W (+ h = tanh z)
+    for l in (0, 1):
+        ctx.upload(l, "ah", ah[l])
+        assert _poison_padding(ctx, l, "ah") > 0
+        ctx.apply_vertex(l, da.FORWARD)
+        z = ctx.download(l, "z")
+        assert np.isfinite(z).all()
+        assert_parity(z, orc.sgemm(ah[l], Ws[l]), what=f"z@{l}")
+        assert_parity(ctx.download(l, "h"), np.tanh(orc.sgemm(ah[l], Ws[l]).astype(np.float64)).astype(np.float32), what=f"h@{l}")
+    # layer 1, backward: g = aTg * (1 - tanh^2 z); dW = ah^T g (TN); grad = g W^T (NT, K = 12 of a 16-deep tile)
+    aTg = rng.uniform(-1, 1, (V, dims[2])).astype(np.float32)
+    ctx.upload(1, "aTg", aTg)
+    for name in ("ah", "aTg", "g", "z"):
+        _poison_padding(ctx, 1, name)
+    ctx.apply_vertex(1, da.BACKWARD)
+    z1 = orc.sgemm(ah[1], Ws[1]).astype(np.float64)
+    g1 = (aTg * (1.0 - np.tanh(z1) ** 2)).astype(np.float32)
+    dW = ctx.weight_grad_get(1)
+    grad = ctx.download(1, "grad")
+    assert np.isfinite(dW).all() and np.isfinite(grad).all()
+    assert_parity(dW, orc.sgemm(ah[1], g1, ta=True), what="dW@1")
+    assert_parity(grad, orc.sgemm(g1, Ws[1], tb=True), what="grad@1")
+    ctx.close()
