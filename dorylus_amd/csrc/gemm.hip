@@ -21,7 +21,6 @@ namespace dory {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 // k-tile depth: 16 (two 16-KB stages per 128-wide workgroup -> 4 workgroups per CU)
 constexpr int BK_SPLIT = 32;   // granularity of the split-K plan
 
@@ -97,7 +96,8 @@ __device__ __forceinline__ void dma_frag(float (&f)[8], const float *img, int bl
 
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs &g, uint32_t klen, float *partial, float *smem) {
-    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    static_assert(WM * WN == 4 && WN * TN * 32 == BN, "tile shape");
+    constexpr int BM = WM * TM * 32;
     constexpr int A_SZ = BM * BK, B_SZ = BN * BK, STAGE = A_SZ + B_SZ;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -184,13 +184,13 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs &g, uint32_t klen, 
 
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs g, uint32_t klen, float *partial) {
-    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BK];
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (WM * TM * 32 + BN) * BK];
     gemm_dma_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
 }
 template <int BN, int WM, int WN, int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int BK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dma_kernel_occ4(GemmArgs g, uint32_t klen,
                                                                                                      float *partial) {
-    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BK];
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (WM * TM * 32 + BN) * BK];
     gemm_dma_body<BN, WM, WN, TM, TN, A_KMAJOR, B_KMAJOR, BK>(g, klen, partial, smem);
 }
 
@@ -218,8 +218,11 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
     }
 }
 
-static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
-    const uint32_t tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+#ifndef GEMM_BM_WIDE
+#define GEMM_BM_WIDE 128   // rows per tile of the 128-wide shape; 64 (finer tail, 6 workgroups per CU) measured: NN 344 -> 339 us, TN 302 -> 348, NT 50 -> 44
+#endif
+static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bm, int bn) {
+    const uint32_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if (tiles == 0) return 1;
     // a workgroup walks its k-tiles one after the other (~1.9 us each): with few tiles even a
     // Cora-sized K (2 708 rows -> 85 k-tiles = 160 us on one workgroup) wants to be split
@@ -233,7 +236,7 @@ static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bn) {
 
 size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K) {
     // only split-K (few output tiles, long K) uses scratch: one M x ld(N) partial per split
-    const uint32_t S = pick_splits(M, N, K, N > 64 ? 128 : 64);
+    const uint32_t S = pick_splits(M, N, K, N > 64 ? GEMM_BM_WIDE : 128, N > 64 ? 128 : 64);   // (the two shapes of launch_gemm)
     return S > 1 ? (size_t)S * M * pad_ld(N) * sizeof(float) : 0;
 }
 
@@ -245,7 +248,8 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
             e = hipMemsetAsync(g.C2, 0, (size_t)g.M * g.ldc2 * sizeof(float), s);
         return e;
     }
-    uint32_t S = pick_splits(g.M, g.N, g.K, BN);
+    constexpr int BM = WM * TM * 32;
+    uint32_t S = pick_splits(g.M, g.N, g.K, BM, BN);
     if (S > 1 && (size_t)S * g.M * g.ldc * sizeof(float) > scratch_bytes) {
         S = (uint32_t)(scratch_bytes / ((size_t)g.M * g.ldc * sizeof(float)));
         if (S < 2) S = 1;
@@ -257,7 +261,7 @@ static hipError_t launch_bn(const GemmArgs &g, float *scratch, size_t scratch_by
     dim3 block(256);
 #define GEMM_LAUNCH(AK, BKM)                                                                                                  \
     do {                                                                                                                      \
-        if constexpr (BN == 128)                                                                                              \
+        if constexpr (BN == 128 && WM * TM * 32 == 128)                                                                       \
             hipLaunchKernelGGL((gemm_dma_kernel_occ4<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch); \
         else                                                                                                                  \
             hipLaunchKernelGGL((gemm_dma_kernel<BN, WM, WN, TM, TN, AK, BKM, BK>), grid, block, 0, s, g, klen, scratch);      \
@@ -285,7 +289,7 @@ hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, 
     // the DMA moves 16-byte pieces: rows must start on 16-byte boundaries (every tensor of the table does: ld is padded to 32 floats)
     if ((g.lda & 3u) || (g.ldb & 3u) || (reinterpret_cast<uintptr_t>(g.A) & 15u) || (reinterpret_cast<uintptr_t>(g.B) & 15u))
         return hipErrorInvalidValue;
-    if (g.N > 64) return launch_bn<128, 2, 2, 2, 2, 16>(g, scratch, scratch_bytes, s);
+    if (g.N > 64) return launch_bn<128, 2, 2, GEMM_BM_WIDE / 64, 2, 16>(g, scratch, scratch_bytes, s);
     return launch_bn<64, 4, 1, 1, 2, 16>(g, scratch, scratch_bytes, s);
 }
 
