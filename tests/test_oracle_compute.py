@@ -168,3 +168,27 @@ def test_xavier_stream_properties():
     x1 = (8888 * 16807) % 2147483647
     u = np.float32(np.float32(x1 - 1) / np.float32(2147483646.0))
     assert abs(w[0, 0] - np.float32((2 * u - 1)) * np.float32(lim)) < 1e-6
+
+
+def test_adam_many_steps_against_torch_adam():
+    """Beyond the one known answer: twelve steps of the restated optimizer against torch.optim.Adam (float64) on the same
+    gradients.  The reference's form (AdamOptimizer.cpp:29-51: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), delta = lr_t m /
+    (sqrt(v) + eps)) is Adam with the epsilon inside the bias correction -- it differs from torch's by eps sqrt(1 - b2^t)
+    in the denominator, i.e. by ~1e-7 / |g| relative: gradients of order 1 must agree to 1e-5, and the float32 state
+    (m, v kept in float32 like the reference's `float` arrays) stays within float32 rounding of the float64 run."""
+    import torch
+    rng = np.random.default_rng(3)
+    n, lr, steps = 257, 0.01, 12
+    w0 = rng.standard_normal(n).astype(np.float32)
+    gs = [(rng.standard_normal(n) * (1.0 + 0.5 * rng.random(n))).astype(np.float32) for _ in range(steps)]
+    w, m, v = w0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    tw = torch.tensor(w0.astype(np.float64), requires_grad=True)
+    opt = torch.optim.Adam([tw], lr=lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.0)
+    for t, g in enumerate(gs, start=1):
+        orc.adam_update(w, g, m, v, lr, t)
+        tw.grad = torch.tensor(g.astype(np.float64))
+        opt.step()
+        ref = tw.detach().numpy()
+        assert np.abs(w - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), t
+    st = opt.state[tw]
+    assert np.abs(m - st["exp_avg"].numpy()).max() < 1e-6 and np.abs(v - st["exp_avg_sq"].numpy()).max() < 1e-6
