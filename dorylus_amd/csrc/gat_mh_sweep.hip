@@ -39,6 +39,9 @@ namespace dory {
 #ifndef GATMH_FWD16_ROWS
 #define GATMH_FWD16_ROWS 2
 #endif
+#ifndef GATMH_FWD_BATCH
+#define GATMH_FWD_BATCH SWEEP_U
+#endif
 #ifndef GATMH_FWD16_BATCH
 #define GATMH_FWD16_BATCH SWEEP_U
 #endif
@@ -46,7 +49,7 @@ namespace dory {
 #define GATMH_SRC16_ROWS 2
 #endif
 #ifndef GATMH_SRC_BATCH
-#define GATMH_SRC_BATCH 4
+#define GATMH_SRC_BATCH 3
 #endif
 constexpr float GATMH_LOG2E = 1.4426950408889634f;
 constexpr float GATMH_DEN_TINY = 1e-30f;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void gatmh_elmax_kernel(uint32_t N, uint32_t G
 template <int GROUP, int HL, int R>
 struct GatFwdSweepOp {
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
-    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : SWEEP_U;
+    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : GATMH_FWD_BATCH;
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;                     // heads per slab of GROUP lanes
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
