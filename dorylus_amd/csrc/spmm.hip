@@ -301,7 +301,10 @@ void free_blocked(BlockedAdj *B) {
 template <bool UNIT>
 struct SweepPlainOp {
     static constexpr bool PLAIN = true, UNIT_W = UNIT, PROLOGUE = false, AUX_BATCH = false;
-    static constexpr int BATCH = SWEEP_U;     // gathers per batch
+#ifndef K1S_BATCH
+#define K1S_BATCH SWEEP_U   // 3 / 4 / 5 / 6 gathers per batch = 18.60 / 18.10 / 18.64 / 19.58 ms per epoch (round 5, re-measured on the final kernel)
+#endif
+    static constexpr int BATCH = K1S_BATCH;     // gathers per batch
     static constexpr int SLACK = SWEEP_SLACK; // windows a workgroup may run ahead of its sweep's slowest
     const float *row_scale;
     struct Row { float4 acc; };
