@@ -121,8 +121,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs &g, uint32_t klen, 
     ta.init(g.A, g.lda, g.M, i0, kbeg, kend);
     tb.init(g.B, g.ldb, g.N, j0, kbeg, kend);
     const uint32_t T = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
-    // (measured and dropped, round 5: starting the first resident set a quarter of a workgroup's duration apart, so that tile
-    // write-backs and first loads of one workgroup fall under another's MFMAs: 351 -> 355 us, nothing)
+    // (measured and dropped, round 5: starting the first resident set apart -- by launch index, then by arrival order on the CU
+    // (HW_ID), an eighth / quarter / half of a workgroup's duration per slot -- so that tile write-backs and first loads of one
+    // workgroup fall under another's MFMAs: 345 -> 348-357 us.  One resident round (M = 131 072) runs at the same fraction of
+    // peak as 1.8 rounds, so workgroup hand-over is not the cost either; what K = 608 loses against K = 4 864 is per tile)
     if (T) { ta.issue(smem); tb.issue(smem + A_SZ); }
     for (uint32_t t = 0; t < T; ++t) {
         // this wave's pieces of tile t have landed; past the barrier everybody's have, and nobody still reads the other stage
