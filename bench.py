@@ -178,11 +178,20 @@ def git_blob_sha1(path):
 
 
 def spmm_source_stamp():
-    """what a PMC traffic figure is stamped with: the sources of the aggregation kernels (K1 / K1s in spmm.hip, the sweep
-    skeleton they run on in sweep_core.hpp since round 5) -- one hash over both blobs"""
+    """what a PMC traffic figure is stamped with: the CODE of the aggregation kernels (K1 / K1s in spmm.hip, the sweep
+    skeleton they run on in sweep_core.hpp since round 5) -- one hash over both files with comments and white space removed,
+    so that a reworded comment does not orphan a measurement while any change the compiler sees does"""
     import hashlib
+    import re
     d = os.path.join(ROOT, "dorylus_amd", "csrc")
-    return hashlib.sha1((git_blob_sha1(os.path.join(d, "spmm.hip")) + git_blob_sha1(os.path.join(d, "sweep_core.hpp"))).encode()).hexdigest()
+    h = hashlib.sha1()
+    for f in ("spmm.hip", "sweep_core.hpp"):
+        with open(os.path.join(d, f), "r", encoding="utf-8") as fh:
+            src = fh.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)      # block comments
+        src = re.sub(r"//[^\n]*", " ", src)                   # line comments (no string literal in these files holds "//")
+        h.update(re.sub(r"\s+", " ", src).encode())
+    return h.hexdigest()
 
 
 def spmm_algorithmic_bytes(N, G, E, F):

@@ -42,3 +42,28 @@ def test_bench_reads_the_committed_projection():
         for P in (2, 4, 8):
             e = bench.scaling_projection_for("reddit", "uniform", P)
             assert e["available"] and e["projected_epoch_ms"] > 0 and e["model"]["link_GBps"] == 153.0
+
+
+def test_pmc_traffic_stamp_follows_code_not_comments(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic is only reported while profiles/pmc_traffic.json was collected for the kernels that are
+    built: the stamp hashes spmm.hip + sweep_core.hpp with comments and white space removed.  The committed figure must carry
+    the stamp of the committed sources (else the driver's line would say `traffic: null`), a reworded comment must not
+    orphan it, a code change must."""
+    import json
+    import shutil
+    import bench
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        d = json.load(f)
+    assert d["spmm_variant_2"]["spmm_hip_blob"] == bench.spmm_source_stamp()
+    csrc = tmp_path / "dorylus_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for f in ("spmm.hip", "sweep_core.hpp"):
+        shutil.copy(os.path.join(ROOT, "dorylus_amd", "csrc", f), csrc / f)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    base = bench.spmm_source_stamp()
+    with open(csrc / "spmm.hip", "a") as f:
+        f.write("\n// a remark\n/* and a block\n   of them */\n")
+    assert bench.spmm_source_stamp() == base
+    with open(csrc / "spmm.hip", "a") as f:
+        f.write("\nstatic int one_more_symbol;\n")
+    assert bench.spmm_source_stamp() != base
