@@ -68,3 +68,15 @@ def test_graphserver_cora_shaped(tmp_path):
     assert len(losses2) == 4 and np.allclose(losses2, losses, rtol=2e-4)
     r3 = subprocess.run(cmd + ["--dory-no_such_option", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert r3.returncode != 0 and "unknown option" in r3.stderr
+
+
+def test_run_dorylus_reference_launcher_line(tmp_path):
+    """`./run/run-dorylus reddit --l=80 --e=3 gpu --t=0.95 --st=5` (benchmarks/run-reddit-gcn:100) on a toy dataset
+    directory under $DORY_FILEPOOL: three epochs run on the device, the ignored knobs are named."""
+    from test_graphserver_cli import _toy_filepool, launch
+    env = _toy_filepool(tmp_path)
+    r = launch(["reddit", "--l=80", "--e=3", "gpu", "--t=0.95", "--st=5"], env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    assert "note: --l=80 --t=0.95 --st=5 ignored by the hip backend" in out
+    assert out.count("batch Acc:") == 3 and "<EM>: Average  sync epoch time" in out
