@@ -23,6 +23,13 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# What the 1e-4 parity criterion does NOT rest on reference-generated numbers for: these pieces are
+# checked against a restatement of the reference's source only -- its own build needs cblas / boost headers the image
+# lacks -- and the 8-head GAT has no reference implementation at all.  Pinned: partition / CSC / CSR indexing (bytes the
+# reference's DataLoader wrote), GCN aggregate + GEMM + tanh + softmax-label + dW (the reference's numpy-gnn), Adam step 1.
+PARITY_UNPINNED = ["gat edge ops (CPU_comm.cpp:161-242,299-408)", "maskout / val-stat (CPU_comm.cpp:464-471)",
+                   "adam beyond step 1 (AdamOptimizer.cpp:29-51)", "xavier stream (weightserver.cpp:567-585)",
+                   "gatmh (8-head softmax GAT: no reference implementation)"]
 sys.path.insert(0, ROOT)
 
 REDDIT_V = 232965
@@ -563,6 +570,7 @@ def main():
             "cached_ah0": cached,
             "spmm_gates": gates,
             "cpu_baseline": cpu,
+            "parity_unpinned": PARITY_UNPINNED,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
             "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1), "multi_gpu": multi,
             "setup_s": round(t_setup, 1),

@@ -43,8 +43,19 @@ def test_bench_json_line_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
     assert cb["gpu_vs_oracle_rel_err_ah0"] < 1e-4
+    up = d["parity_unpinned"]     # what 1e-4 does not cover with reference-generated numbers, stated in the line itself
+    assert isinstance(up, list) and len(up) == 5 and all(isinstance(x, str) for x in up)
+    for word in ("gat edge ops", "maskout", "adam", "xavier", "gatmh"):
+        assert any(word in x for x in up), word
     tf = d["transform_first"]
     assert tf is None or tf["ms_per_step"] > 0
+
+
+def test_parity_unpinned_is_declared_without_a_gpu():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert len(bench.PARITY_UNPINNED) == 5 and any("gatmh" in x for x in bench.PARITY_UNPINNED)
+    assert '"parity_unpinned": PARITY_UNPINNED' in open(os.path.join(ROOT, "bench.py")).read()
 
 
 def test_stdout_is_shielded_while_communicators_are_created():
