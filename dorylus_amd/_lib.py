@@ -24,7 +24,7 @@ SYMBOLS = [
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
     "dory_epoch_graph_begin", "dory_epoch_graph_end", "dory_epoch_graph_launch", "dory_epoch_graph_drop",
     "dory_gatmh_heads", "dory_transform_first_active", "dory_transform_first_layer",
-    "dory_comm_set_host_transport", "dory_debug_occupy_cus",
+    "dory_comm_set_host_transport", "dory_comm_init_local", "dory_debug_occupy_cus",
 ]
 
 # host transport callbacks (include/dorylus_hip.h)
@@ -94,6 +94,7 @@ def load():
         "dory_ctx_describe": [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
         "dory_gatmh_heads": [vp, vp],
         "dory_comm_set_host_transport": [vp, ALLTOALLV_FN, ALLREDUCE_FN, vp],
+        "dory_comm_init_local": [vp, C.c_uint32],
         # include/dorylus_host.h
         "dory_partition_build": [vp, vp, u64, vp, u32, u32, u32, i32, C.POINTER(vp)],
         "dory_partition_build_from_files": [cp, u32, u32, i32, C.POINTER(vp)],
@@ -293,6 +294,17 @@ class Context:
     def comm_init(self, id128, rank, nranks):
         b = np.ascontiguousarray(id128, np.uint8)
         self._ck(self.lib.dory_comm_init(self.h, _ptr(b), rank, nranks))
+
+    @staticmethod
+    def comm_init_local(ctxs):
+        """in-process device transport: the contexts (rank i = ctxs[i]) of this process become each other's peers -- rows
+        travel device -> device on the sender's comm stream, ordered by cross-context events (dory_comm_init_local).
+        Drive each rank from its own thread afterwards (ctypes calls release the GIL)."""
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        rc = ctxs[0].lib.dory_comm_init_local(arr, len(ctxs))
+        if rc != 0:
+            msgs = [c.lib.dory_last_error(c.h).decode() for c in ctxs]
+            raise DoryError(f"dory_comm_init_local failed ({rc}): " + "; ".join(m for m in msgs if m))
 
     def set_host_transport(self, alltoallv, allreduce):
         """alltoallv(send: np.ndarray, send_counts, send_offsets, recv: np.ndarray, recv_counts, recv_offsets) and

@@ -4,7 +4,229 @@
 
 using namespace dory;
 
+#include <chrono>
+#include <thread>
+
+// ---------------------------------------------------------------------------------------
+// In-process device transport (dory_comm_init_local): P contexts of one process on one device are each other's peers.
+// One exchange = pack on the sender's comm stream -> hipMemcpyAsync device -> device into every peer's receive buffer on
+// the SENDER's comm stream -> event "sent"; the receiver's comm stream waits for its peers' "sent" events, unpacks, records
+// "consumed" (its receive buffer is free again) and the event the compute stream waits for.  Same stream / event structure
+// as the RCCL arm, no host synchronisation with the device anywhere: what the overlapped schedule of Engine::scatterGCN +
+// ghostReceiver (gcn_ops.cpp:204-282 send, :284-362 receive) looks like when copies really run beside the aggregation.
+// A stream never waits for an event that is not recorded yet (hipStreamWaitEvent on an unrecorded event is a no-op, and a
+// device-side wait for work a host thread has still to enqueue deadlocks with any device-wide synchronisation, e.g. a
+// hipFree in a lazy allocation): every event has a progress counter its owner bumps AFTER recording, and a context reads
+// the peer's counter BEFORE it makes its stream wait.  That read may block the calling host thread until the peer's host
+// thread has got there (bounded: option local_timeout_ms) -- so the ranks must be driven by one host thread each, or stage
+// by stage (all ranks' scatter before any rank's next gather), exactly as real ranks are.
+namespace {
+
+constexpr uint32_t LOCAL_MAX_RANKS = 16;
+
+int local_wait_posted(dory_ctx *c, const std::atomic<uint64_t> &ctr, uint64_t want, uint32_t peer, const char *what) {
+    if (ctr.load(std::memory_order_acquire) >= want) return DORY_OK;
+    const int64_t lim = c->opt["local_timeout_ms"] > 0 ? c->opt["local_timeout_ms"] : 30000;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(lim);
+    uint32_t spins = 0;
+    while (ctr.load(std::memory_order_acquire) < want) {
+        if (++spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() > deadline)
+            return fail(c, DORY_ERR_COMM, "local transport: rank %u did not reach %s %llu within %lld ms (every rank needs its own host thread, or "
+                        "stage-by-stage driving)", peer, what, (unsigned long long)want, (long long)lim);
+    }
+    return DORY_OK;
+}
+
+// an interval for dory_timing_get whose end is recorded by a later call: entry pushed now (order of `pending` = order of
+// the first events), end event handed back
+void timed_open(dory_ctx *c, const char *fam, hipStream_t s, hipEvent_t *end_out) {
+    *end_out = nullptr;
+    if (!c->timing || c->capturing) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->ev_pool.empty()) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    } else {
+        a = c->ev_pool.back().first;
+        b = c->ev_pool.back().second;
+        c->ev_pool.pop_back();
+    }
+    (void)hipEventRecord(a, s);
+    c->pending.push_back({fam, a, b});
+    *end_out = b;
+}
+
+struct PeerPtrs { const float *p[LOCAL_MAX_RANKS]; };
+__global__ __launch_bounds__(256) void local_sum_kernel(PeerPtrs pp, uint32_t P, uint64_t n, float *out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float sum = 0.f;
+        for (uint32_t q = 0; q < P; ++q) sum += pp.p[q][i];      // rank order on every rank: identical bits everywhere
+        out[i] = sum;
+    }
+}
+
+}  // namespace
+
+namespace dory {
+
+// second half of an exchange: the peers' rows have been sent (their "sent" events) -> unpack -> "consumed" + ev_b
+int local_exchange_finish(dory_ctx *c) {
+    dory_ctx::LocalPending &lp = c->local_pending;
+    if (!lp.on) return DORY_OK;
+    HaloPlan &p = c->plan[lp.dir];
+    const uint64_t s = c->local_seq;
+    LocalGroup &grp = *c->local;
+    for (uint32_t q = 0; q < c->numNodes; ++q) {
+        if (q == c->nodeId) continue;
+        dory_ctx *Q = grp.ctx[q];
+        if (!Q) return fail(c, DORY_ERR_COMM, "local transport: rank %u has been destroyed", q);
+        int rc = local_wait_posted(c, Q->posted_sent, s, q, "exchange");
+        if (rc) return rc;
+        HIPCK(c, hipStreamWaitEvent(c->comm, Q->ev_sent[s & 1], 0));
+    }
+    lp.on = false;     // (a peer that has not arrived leaves the second half pending: the caller may try again)
+    HIPCK(c, launch_scatter_rows(lp.ghost, c->recv_buf, lp.ghost_ld, lp.w, p.d_recv_slots, p.recv_total, c->comm));
+    HIPCK(c, hipEventRecord(c->ev_cons[s & 1], c->comm));
+    c->posted_cons.store(s, std::memory_order_release);
+    if (lp.t_kind_b) (void)hipEventRecord(lp.t_kind_b, c->comm);
+    if (lp.t_halo_b) (void)hipEventRecord(lp.t_halo_b, c->comm);
+    lp.t_kind_b = lp.t_halo_b = nullptr;
+    HIPCK(c, hipEventRecord(c->ev_b, c->comm));
+    return DORY_OK;
+}
+
+// first half: pack, push my rows into every peer's receive buffer, "sent"
+static int local_exchange_send(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, uint32_t w, bool deferred) {
+    HaloPlan &p = c->plan[dir];
+    LocalGroup &grp = *c->local;
+    if (c->local_pending.on) {   // (not reached: every consumer and every exchange calls wait_halo first)
+        int rc = local_exchange_finish(c);
+        if (rc) return rc;
+    }
+    const uint64_t s = ++c->local_seq;
+    dory_ctx::LocalPending &lp = c->local_pending;
+    timed_open(c, "halo", c->comm, &lp.t_halo_b);
+    timed_open(c, deferred ? "halo_deferred" : "halo_waited", c->comm, &lp.t_kind_b);
+    HIPCK(c, launch_gather_rows(c->send_buf, src->d, src->ld, w, p.d_send_lvids, p.send_total, c->comm));
+    for (uint32_t q = 0; q < c->numNodes; ++q) {
+        if (q == c->nodeId || !p.send_counts[q]) continue;
+        dory_ctx *Q = grp.ctx[q];
+        if (!Q) return fail(c, DORY_ERR_COMM, "local transport: rank %u has been destroyed", q);
+        const HaloPlan &pq = Q->plan[dir];
+        if (!pq.set || pq.recv_counts.size() != c->numNodes || pq.recv_counts[c->nodeId] != p.send_counts[q])
+            return fail(c, DORY_ERR_COMM, "local transport: rank %u expects %u rows from rank %u, which sends %u", q,
+                        pq.set && pq.recv_counts.size() == c->numNodes ? pq.recv_counts[c->nodeId] : 0u, c->nodeId, p.send_counts[q]);
+        if ((size_t)pq.recv_total * w * sizeof(float) > Q->recv_cap)
+            return fail(c, DORY_ERR_COMM, "local transport: receive buffer of rank %u too small for %u-float rows", q, w);
+        if (s > 1) {   // its receive buffer must have been unpacked (exchange s - 1)
+            int rc = local_wait_posted(c, Q->posted_cons, s - 1, q, "the unpack of exchange");
+            if (rc) return rc;
+            HIPCK(c, hipStreamWaitEvent(c->comm, Q->ev_cons[(s - 1) & 1], 0));
+        }
+        HIPCK(c, hipMemcpyAsync(Q->recv_buf + (size_t)pq.recv_off[c->nodeId] * w, c->send_buf + (size_t)p.send_off[q] * w,
+                                (size_t)p.send_counts[q] * w * sizeof(float), hipMemcpyDeviceToDevice, c->comm));
+    }
+    HIPCK(c, hipEventRecord(c->ev_sent[s & 1], c->comm));
+    c->posted_sent.store(s, std::memory_order_release);
+    lp.on = true;
+    lp.dir = dir;
+    lp.ghost = ghost->d;
+    lp.ghost_ld = ghost->ld;
+    lp.w = w;
+    if (deferred) {
+        c->halo_pending = true;      // wait_halo(): local_exchange_finish, then the compute stream waits for ev_b
+        return DORY_OK;
+    }
+    int rc = local_exchange_finish(c);
+    if (rc) return rc;
+    HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
+    return DORY_OK;
+}
+
+// weight-gradient sum over the group: every rank adds the P gradients in rank order (identical bits on every rank)
+static int local_allreduce(dory_ctx *c, uint32_t layer, const std::string &name, Tensor &g, uint64_t n) {
+    LocalGroup &grp = *c->local;
+    const uint32_t P = c->numNodes;
+    if (n * sizeof(float) > c->ar_tmp_cap) return fail(c, DORY_ERR_COMM, "local transport: gradient staging buffer too small (preallocate before dory_comm_init_local)");
+    const uint64_t t = ++c->local_ar_seq;
+    HIPCK(c, hipEventRecord(c->ev_gready[t & 1], c->compute));
+    c->posted_g.store(t, std::memory_order_release);
+    PeerPtrs pp{};
+    for (uint32_t q = 0; q < P; ++q) {
+        dory_ctx *Q = q == c->nodeId ? c : grp.ctx[q];
+        if (!Q) return fail(c, DORY_ERR_COMM, "local transport: rank %u has been destroyed", q);
+        if (q != c->nodeId) {
+            int rc = local_wait_posted(c, Q->posted_g, t, q, "gradient sum");
+            if (rc) return rc;
+            HIPCK(c, hipStreamWaitEvent(c->compute, Q->ev_gready[t & 1], 0));
+        }
+        if (layer >= Q->wgrads.size()) return fail(c, DORY_ERR_COMM, "local transport: rank %u has no layer %u", q, layer);
+        auto it = Q->wgrads[layer].find(name);
+        if (it == Q->wgrads[layer].end() || (uint64_t)it->second.rows * it->second.ld != n)
+            return fail(c, DORY_ERR_COMM, "local transport: rank %u's gradient '%s'@%u has another shape", q, name.c_str(), layer);
+        pp.p[q] = it->second.d;
+    }
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(local_sum_kernel, dim3(blocks), dim3(256), 0, c->compute, pp, P, n, c->ar_tmp);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(c->ev_gdone[t & 1], c->compute));
+    c->posted_gdone.store(t, std::memory_order_release);
+    for (uint32_t q = 0; q < P; ++q) {     // nobody reads my gradient any more: the sum may replace it
+        if (q == c->nodeId) continue;
+        dory_ctx *Q = grp.ctx[q];
+        int rc = local_wait_posted(c, Q->posted_gdone, t, q, "the end of gradient sum");
+        if (rc) return rc;
+        HIPCK(c, hipStreamWaitEvent(c->compute, Q->ev_gdone[t & 1], 0));
+    }
+    HIPCK(c, hipMemcpyAsync(g.d, c->ar_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, c->compute));
+    return DORY_OK;
+}
+
+}  // namespace dory
+
 extern "C" {
+
+int dory_comm_init_local(dory_ctx *const *ctxs, uint32_t n) {
+    if (!ctxs || n < 2 || n > LOCAL_MAX_RANKS) return DORY_ERR_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        dory_ctx *c = ctxs[i];
+        if (!c) return DORY_ERR_ARG;
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!c->configured || c->numNodes != n || c->nodeId != i)
+            return fail(c, DORY_ERR_ARG, "comm_init_local: context %u must be configured as rank %u of %u", i, i, n);
+        if (c->device != ctxs[0]->device) return fail(c, DORY_ERR_ARG, "comm_init_local: all contexts on one device");
+        if (!c->plan[0].set || !c->plan[1].set) return fail(c, DORY_ERR_ARG, "comm_init_local: halo plans first (dory_partition_upload / dory_halo_plan)");
+        if (!c->prealloc) return fail(c, DORY_ERR_ARG, "comm_init_local: dory_preallocate first");
+    }
+    auto grp = std::make_shared<LocalGroup>();
+    grp->ctx.assign(ctxs, ctxs + n);
+    for (uint32_t i = 0; i < n; ++i) {
+        dory_ctx *c = ctxs[i];
+        std::lock_guard<std::mutex> lock(c->mu);
+        HIPCK(c, hipSetDevice(c->device));
+        HIPCK(c, hipStreamSynchronize(c->compute));
+        HIPCK(c, hipStreamSynchronize(c->comm));
+        for (hipEvent_t *e : {&c->ev_sent[0], &c->ev_sent[1], &c->ev_cons[0], &c->ev_cons[1], &c->ev_gready[0], &c->ev_gready[1],
+                              &c->ev_gdone[0], &c->ev_gdone[1]})
+            if (!*e) HIPCK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        size_t need = 0;
+        for (auto &m : c->wgrads)
+            for (auto &kv : m) need = std::max(need, (size_t)kv.second.rows * kv.second.ld * sizeof(float));
+        if (need > c->ar_tmp_cap) {
+            if (c->ar_tmp) (void)hipFree(c->ar_tmp);
+            c->ar_tmp = nullptr; c->ar_tmp_cap = 0;
+            HIPCK(c, hipMalloc((void **)&c->ar_tmp, need));
+            c->ar_tmp_cap = need;
+        }
+        c->posted_sent = 0; c->posted_cons = 0; c->posted_g = 0; c->posted_gdone = 0;
+        c->local_seq = c->local_ar_seq = 0;
+        c->local_pending = dory_ctx::LocalPending();
+        c->local = grp;
+    }
+    return DORY_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 int dory_halo_plan(dory_ctx *c, int dir, const uint32_t *send_counts, const uint32_t *send_lvids,
@@ -154,13 +376,16 @@ namespace dory {
 int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) {
     HaloPlan &p = c->plan[dir];
     if (!p.set) return fail(c, DORY_ERR_ARG, "halo_exchange: no plan");
-    if (!c->tx_a2a) {
+    const bool local = !c->tx_a2a && c->local;
+    if (!c->tx_a2a && !local) {
         if (!c->nccl) return fail(c, DORY_ERR_COMM, "halo_exchange: dory_comm_init not called");
         if (c->nranks != (int)c->numNodes) return fail(c, DORY_ERR_COMM, "halo_exchange: communicator size != num_nodes");
     }
     if (src->ld != ghost->ld) return fail(c, DORY_ERR_ARG, "halo_exchange: row widths of source and ghost tensor differ");
     const uint32_t w = src->ld;  // padded row width travels (keeps 16-B lanes)
     const size_t sb = (size_t)p.send_total * w * sizeof(float), rb = (size_t)p.recv_total * w * sizeof(float);
+    if (local && (sb > c->send_cap || rb > c->recv_cap))
+        return fail(c, DORY_ERR_COMM, "local transport: exchange buffers too small for %u-float rows (peers hold their addresses: no regrowth)", w);
     if (sb > c->send_cap || rb > c->recv_cap) {   // not reached after dory_halo_plan sized them for the widest layer (a
         HIPCK(c, hipDeviceSynchronize());          // tensor uploaded with other dimensions than dory_configure's)
         if (sb > c->send_cap) {
@@ -179,6 +404,7 @@ int exchange_rows(dory_ctx *c, int dir, Tensor *src, Tensor *ghost, bool defer) 
     // comm stream waits for the producer of `src` on the compute stream
     HIPCK(c, hipEventRecord(c->ev_a, c->compute));
     HIPCK(c, hipStreamWaitEvent(c->comm, c->ev_a, 0));
+    if (local) return local_exchange_send(c, dir, src, ghost, w, defer && c->opt["halo_overlap"]);
     {
         Timed t(c, "halo", c->comm);
         Timed td(c, (defer && c->opt["halo_overlap"]) ? "halo_deferred" : "halo_waited", c->comm);   // (overlap bookkeeping: abi_internal.hpp)
@@ -299,6 +525,10 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
             if (c->tx_ar(c->tx_user, c->tx_send.data(), n)) return fail(c, DORY_ERR_COMM, "weight_update: host transport allreduce failed");
             HIPCK(c, hipMemcpyAsync(g.d, c->tx_send.data(), n * sizeof(float), hipMemcpyHostToDevice, c->compute));
             HIPCK(c, hipStreamSynchronize(c->compute));
+        } else if (c->numNodes > 1 && c->local) {
+            Timed t(c, "allreduce", c->compute);
+            int rc = local_allreduce(c, layer, name, g, n);
+            if (rc) return rc;
         } else if (c->numNodes > 1) {
             if (!c->nccl) return fail(c, DORY_ERR_COMM, "weight_update: dory_comm_init not called");
             // sum of per-partition updates (WeightTensor::localUpdate/ghostUpdate,

@@ -117,6 +117,10 @@ int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const 
 // compute stream is only made to wait for them (event ev_b) by the first consumer.
 int wait_halo(dory_ctx *c) {
     if (c->halo_pending) {
+        if (c->local_pending.on) {   // in-process device transport: the peers' rows, unpack, ev_b
+            int rc = local_exchange_finish(c);
+            if (rc) return rc;
+        }
         HIPCK(c, hipStreamWaitEvent(c->compute, c->ev_b, 0));
         c->halo_pending = false;
     }
@@ -205,6 +209,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["local_timeout_ms"] = 30000;   // in-process device transport: how long a rank's host thread waits for a peer's host thread
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
     c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
@@ -257,6 +262,13 @@ int dory_destroy(dory_ctx *c) {
     drain_timing(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
+    if (c->local) {   // leave the group: peers find a null entry, not a dangling pointer
+        std::lock_guard<std::mutex> lk(c->local->mu);
+        for (auto &q : c->local->ctx) if (q == c) q = nullptr;
+    }
+    for (hipEvent_t e : {c->ev_sent[0], c->ev_sent[1], c->ev_cons[0], c->ev_cons[1], c->ev_gready[0], c->ev_gready[1], c->ev_gdone[0], c->ev_gdone[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (c->ar_tmp) (void)hipFree(c->ar_tmp);
     free_table(c->tensors);
     free_table(c->weights);
     free_table(c->wgrads);
@@ -305,6 +317,7 @@ int dory_set_streams(dory_ctx *c, void *compute_stream, void *comm_stream) {
 
 int dory_sync(dory_ctx *c) {
     CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }   // (a deferred exchange nobody consumed yet: its ghosts land first)
     HIPCK(c, hipStreamSynchronize(c->compute));
     HIPCK(c, hipStreamSynchronize(c->comm));
     c->halo_pending = false;   // everything has landed
@@ -544,8 +557,12 @@ int dory_preallocate(dory_ctx *c) {
         size_t need = 0;
         for (const BlockedAdj *S : {&c->swpIn, &c->swpOut})
             if (S->nb)
-                for (int g_ : {16, 32})   // (launches walk fewer rows per group than the layout deals: more sweeps, more counters; 2 is the least)
-                    need = std::max(need, sweep_scratch_bytes(*S, g_ == 32 ? maxld : std::min<uint32_t>(maxld, 64u), g_, std::min<uint32_t>(32u, c->cus_per_xcd), S->nb, 2));
+                for (uint32_t l = 0; l < L; ++l) {   // every layer's own launch shape: its leading dimension (a 96-float layer runs 16-lane
+                    // groups on two slabs) and the group blk_group_for() gives it; launches walk fewer rows per group than the
+                    // layout deals (more sweeps, more counters): 2 is the least
+                    const uint32_t ld_l = pad_ld(l == L - 1 ? d[l + 1] * c->heads[l] : d[l + 1]);
+                    need = std::max(need, sweep_scratch_bytes(*S, ld_l, blk_group_for(c, ld_l), std::min<uint32_t>(32u, c->cus_per_xcd), S->nb, 2));
+                }
         if (need > c->partial_bytes) {
             if (c->partial) (void)hipFree(c->partial);
             c->partial = nullptr;
@@ -793,6 +810,7 @@ int dory_timing_get(dory_ctx *c, const char *family, double *total_ms, uint64_t 
     if (!family) return DORY_ERR_ARG;
     if (!strcmp(family, "spmm_gate_timeouts")) {   // not a kernel family: launches = gate timeouts, total_ms = ungated launches
         uint32_t st[4] = {0, 0, 0, 0};
+        if (c->capturing) return fail(c, DORY_ERR_ARG, "spmm_gate_timeouts: not while an epoch graph is being recorded (reading synchronises the stream)");
         HIPCK(c, hipStreamSynchronize(c->compute));
         HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
         if (total_ms) *total_ms = (double)st[2];
@@ -841,6 +859,7 @@ int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     // backed off after a timeout (same results, unsynchronised rate)
     if (key && value && !strcmp(key, "spmm_gates_rearm")) {   // (write-only action; reads as "is a back-off pending": launch number below a horizon)
         uint32_t st[SWEEP_STAT_WORDS] = {0};
+        if (c->capturing) return fail(c, DORY_ERR_ARG, "spmm_gates_rearm: not while an epoch graph is being recorded (reading synchronises the stream)");
         HIPCK(c, hipStreamSynchronize(c->compute));
         HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
         *value = (st[4] < st[1] || st[4] < st[3]) ? 1 : 0;
@@ -853,6 +872,7 @@ int dory_get_option(dory_ctx *c, const char *key, int64_t *value) {
     if (key && value && !strcmp(key, "spmm_xcd_ungated_us")) { *value = (int64_t)(c->xcd_ungated_ms * 1e3f); return DORY_OK; }
     if (key && value && (!strcmp(key, "spmm_gate_timeouts") || !strcmp(key, "spmm_ungated_launches"))) {
         uint32_t st[4] = {0, 0, 0, 0};
+        if (c->capturing) return fail(c, DORY_ERR_ARG, "%s: not while an epoch graph is being recorded (reading synchronises the stream)", key);
         HIPCK(c, hipStreamSynchronize(c->compute));
         HIPCK(c, hipMemcpy(st, c->sweep_stat, sizeof(st), hipMemcpyDeviceToHost));
         *value = !strcmp(key, "spmm_gate_timeouts") ? st[0] : st[2];

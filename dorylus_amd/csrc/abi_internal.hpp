@@ -96,6 +96,8 @@ int upload_array(dory_ctx *c, T **dst, const T *src, uint64_t n) {
 // Ghost rows of the last halo exchange land on the comm stream; with "halo_overlap" the compute stream is only
 // made to wait for them (event ev_b) by the first consumer.
 int wait_halo(dory_ctx *c);
+// in-process device transport: second half of a deferred exchange (abi_comm.hip); wait_halo and dory_sync run it
+int local_exchange_finish(dory_ctx *c);
 // transform-first order applies to this GCN layer (option, model shape, adjacency values): see abi_context.hip
 bool tf_layer(dory_ctx *c, uint32_t layer);
 bool tf_active(dory_ctx *c);   // = tf_layer(c, 0)

@@ -147,7 +147,6 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 c->partial_bytes = need;
             }
             if (S.nslots && (rc = ensure_scratch(c, (size_t)S.nslots * a.ld * sizeof(float)))) return rc;   // pieces of split rows
-            Timed t(c, "spmm", c->compute);
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
             uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
             SweepCtl ctl;
@@ -157,26 +156,31 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
             ctl.loader = c->opt["spmm_sweep_loader"] != 0;
             SpmmArgs a1 = a;          // the pieces' slots are written, not accumulated, by the first launch
             // placement check failed (ctx.hpp): gates would synchronise workgroups that do not share an L2.  Decide once, by
-            // measurement, on a launch that may be repeated (it writes, does not accumulate): gated against ungated
+            // measurement, on a launch that may be repeated (it writes, does not accumulate): gated against ungated.  The
+            // three probe launches are timed under their own key ("spmm_xcd_probe"), outside the caller's "spmm" region.
             if ((!c->xcd_mapping_ok || c->opt["spmm_xcd_assume_mismatch"]) && !(sflags & 8u)) {
                 if (c->xcd_policy < 0 && !c->capturing && !a.accumulate && !c->halo_pending) {
-                    hipEvent_t e0, e1, e2;
-                    HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1)); HIPCK(c, hipEventCreate(&e2));
+                    struct Ev3 {   // destroyed on every way out (HIPCK returns)
+                        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+                        ~Ev3() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+                    } ev;
+                    Timed tp(c, "spmm_xcd_probe", c->compute);
+                    for (auto &x : ev.e) HIPCK(c, hipEventCreate(&x));
                     const uint32_t hi = two ? S.nb_local : S.nb;
                     HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags | 8u, c->scratch));   // (warm: layout, code)
-                    HIPCK(c, hipEventRecord(e0, c->compute));
+                    HIPCK(c, hipEventRecord(ev.e[0], c->compute));
                     HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags, c->scratch));
-                    HIPCK(c, hipEventRecord(e1, c->compute));
+                    HIPCK(c, hipEventRecord(ev.e[1], c->compute));
                     HIPCK(c, launch_spmm_sweep(a1, S, group, row_scale, G, 0, hi, done, c->compute, ctl, sflags | 8u, c->scratch));
-                    HIPCK(c, hipEventRecord(e2, c->compute));
-                    HIPCK(c, hipEventSynchronize(e2));
-                    (void)hipEventElapsedTime(&c->xcd_gated_ms, e0, e1);
-                    (void)hipEventElapsedTime(&c->xcd_ungated_ms, e1, e2);
-                    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+                    HIPCK(c, hipEventRecord(ev.e[2], c->compute));
+                    HIPCK(c, hipEventSynchronize(ev.e[2]));
+                    (void)hipEventElapsedTime(&c->xcd_gated_ms, ev.e[0], ev.e[1]);
+                    (void)hipEventElapsedTime(&c->xcd_ungated_ms, ev.e[1], ev.e[2]);
                     c->xcd_policy = c->xcd_gated_ms <= c->xcd_ungated_ms ? 0 : 8;
                 }
                 sflags |= c->xcd_policy == 0 ? 0u : 8u;      // undecided (recording, accumulating caller): ungated, never a timeout
             }
+            Timed t(c, "spmm", c->compute);
             if (two) {
                 // under an exchange in flight the RCCL kernels need CUs of their own
                 const uint32_t reserve = c->halo_pending ? (uint32_t)c->opt["spmm_sweep_reserve_cus"] : 0u;

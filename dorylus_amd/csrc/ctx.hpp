@@ -3,8 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -81,6 +83,12 @@ struct LongRowsHost {                    // plan_long_rows output
 struct LongRowsDev {
     uint32_t nrows = 0, nchunks = 0;
     uint32_t *rows = nullptr, *row_chunk_ptr = nullptr, *chunks = nullptr;
+};
+// In-process device transport (dory_comm_init_local, abi_comm.hip): the contexts of one process that are each other's
+// peers.  Peers read each other's plans, buffers, events and progress counters; nothing else.
+struct LocalGroup {
+    std::mutex mu;                    // membership only (a context leaving at dory_destroy)
+    std::vector<dory_ctx *> ctx;      // by rank; nullptr once destroyed
 };
 struct AdamState {
     float lr = 0.01f;
@@ -179,6 +187,25 @@ struct dory_ctx {
     void *tx_user = nullptr;
     std::vector<float> tx_send, tx_recv;
     int rank = 0, nranks = 1;
+    // in-process device transport (dory_comm_init_local): rows travel device -> device on the sender's comm stream, ordered
+    // by cross-context events; a context only ever waits (on the device) for events its peer has ALREADY recorded -- the
+    // host side checks the peer's progress counter first -- so no stream depends on a host call still to come
+    std::shared_ptr<dory::LocalGroup> local;
+    hipEvent_t ev_sent[2] = {nullptr, nullptr};    // [seq & 1]: my rows of exchange seq have landed in the peers' receive buffers
+    hipEvent_t ev_cons[2] = {nullptr, nullptr};    // [seq & 1]: my receive buffer of exchange seq has been unpacked
+    hipEvent_t ev_gready[2] = {nullptr, nullptr};  // [seq & 1]: my weight gradient of sum seq is final
+    hipEvent_t ev_gdone[2] = {nullptr, nullptr};   // [seq & 1]: I have read every peer's gradient of sum seq
+    std::atomic<uint64_t> posted_sent{0}, posted_cons{0}, posted_g{0}, posted_gdone{0};   // last seq whose event is recorded
+    uint64_t local_seq = 0, local_ar_seq = 0;      // exchanges / gradient sums issued so far
+    struct LocalPending {                           // second half of a deferred exchange (wait for the peers' rows, unpack)
+        bool on = false;
+        int dir = 0;
+        float *ghost = nullptr;
+        uint32_t ghost_ld = 0, w = 0;
+        hipEvent_t t_halo_b = nullptr, t_kind_b = nullptr;   // timing: end events of the "halo" / "halo_deferred|waited" intervals
+    } local_pending;
+    float *ar_tmp = nullptr;          // gradient sum before it replaces the local gradient
+    size_t ar_tmp_cap = 0;
 
     // epoch graph (hipGraph replay of one captured epoch; single partition)
     bool capturing = false;

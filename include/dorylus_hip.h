@@ -183,6 +183,16 @@ typedef int (*dory_alltoallv_fn)(void *user, const float *send, const uint64_t *
                                  float *recv, const uint64_t *recv_counts, const uint64_t *recv_offsets, uint32_t num_nodes);
 typedef int (*dory_allreduce_fn)(void *user, float *buf, uint64_t n);
 int dory_comm_set_host_transport(dory_ctx *ctx, dory_alltoallv_fn alltoallv, dory_allreduce_fn allreduce_sum, void *user);
+/* In-process device transport: the `n` contexts (rank i = ctxs[i], all configured with num_nodes == n, graphs and halo
+ * plans uploaded, preallocated, on ONE device) become each other's peers.  An exchange is then pack -> hipMemcpyAsync
+ * device -> device into every peer's receive buffer on the SENDER's comm stream -> cross-context events -> unpack on the
+ * receiver's comm stream; the gradient sum reads the peers' gradients in rank order.  Same stream / event structure as the
+ * RCCL path and no host synchronisation with the device: the overlapped schedule of Engine::scatterGCN + ghostReceiver
+ * (gcn_ops.cpp:204-282 send, :284-362 receive) with copies that really run beside the aggregation, on one GPU.  Drive
+ * every rank from its own host thread (as real ranks are), or stage by stage; a rank whose peer's host thread never
+ * arrives fails with DORY_ERR_COMM after option local_timeout_ms (default 30 s).  Destroy the contexts only after all of
+ * them are synchronised.  A host transport set on a context takes precedence; RCCL is not used. */
+int dory_comm_init_local(dory_ctx *const *ctxs, uint32_t n);
 /* pack -> grouped ncclSend/ncclRecv (all-to-all-v) -> unpack into fg / bg
  * (GCN: fwd sends h@(layer-1) into fg@layer, bwd sends grad@layer into bg@(layer-1);
  *  GAT: fwd z@(layer-1) -> fg_z@(layer-1), bwd grad@(layer-1) -> bg_d@(layer-1);
