@@ -98,6 +98,23 @@ std::vector<uint32_t> degree_order(const uint64_t *ptr, uint32_t N) {
     return o;
 }
 
+// rows in the order of their MEDIAN source id (option spmm_order = 3, round 6 experiment): waves that run at the same time then
+// read source rows from the same neighbourhood of the [local ; ghost] row space -- if the graph has one.  Per-row results are
+// bit-identical whatever the schedule.
+std::vector<uint32_t> median_source_order(const uint64_t *ptr, const uint32_t *idx, uint32_t N) {
+    std::vector<uint32_t> med(N), o(N), tmp;
+    for (uint32_t v = 0; v < N; ++v) {
+        const uint64_t e0 = ptr[v], e1 = ptr[v + 1];
+        if (e0 == e1) { med[v] = 0xFFFFFFFFu; continue; }
+        tmp.assign(idx + e0, idx + e1);
+        std::nth_element(tmp.begin(), tmp.begin() + (tmp.size() / 2), tmp.end());
+        med[v] = tmp[tmp.size() / 2];
+    }
+    std::iota(o.begin(), o.end(), 0u);
+    std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return med[a] < med[b]; });
+    return o;
+}
+
 int gemm(dory_ctx *c, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, const Tensor &A,
          const Tensor &B, Tensor &C, Tensor *C2) {
     GemmArgs g{};
@@ -205,10 +222,12 @@ int dory_create(int device, dory_ctx **out) {
     }
     c->opt["spmm_xcd_assume_mismatch"] = 0;  // testing: treat the placement check as failed (the gated / ungated choice is then made by measurement)
     c->opt["spmm_slab"] = 0;
-    c->opt["spmm_order"] = 1;    // K1: rows longest first -- 1 = when the degrees are skewed (max > 8 x mean), 2 = always, 0 = never
+    c->opt["spmm_order"] = 1;    // K1: rows longest first -- 1 = when the degrees are skewed (max > 8 x mean), 2 = always, 0 = never;
+                                 // 3 (before dory_graph_upload) = rows by their median source id instead (experiment, profiles/HISTORY.md)
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["spmm_sweep_cus"] = 0;         // K1s / GAT sweeps: workgroups per sweep and XCD (0 = all CUs of an XCD); see dory_set_option
     c->opt["local_timeout_ms"] = 30000;   // in-process device transport: how long a rank's host thread waits for a peer's host thread
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
     c->opt["gatmh_bwd_phase"] = 0;       // multi-head GAT backward: 0 = whole sweep (exchanging the ghost rows itself), 1 / 2 = first / second phase only (callers with their own transport)
@@ -383,7 +402,9 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
     if ((rc = upload_array(c, &c->colIdx, column_idxs, nnz_out))) return rc;
     if ((rc = upload_array(c, &c->csrVal, csr_values, nnz_out))) return rc;
     if ((rc = upload_array(c, &c->norm, vtx_norms, (uint64_t)N))) return rc;
-    auto oi = degree_order(column_ptrs, N), oo = degree_order(row_ptrs, N);
+    const bool by_median = c->opt["spmm_order"] == 3;    // (set before the upload: the schedule is built here)
+    auto oi = by_median ? median_source_order(column_ptrs, row_idxs, N) : degree_order(column_ptrs, N);
+    auto oo = by_median ? median_source_order(row_ptrs, column_idxs, N) : degree_order(row_ptrs, N);
     {   // is the degree distribution skewed enough for the longest-first row schedule to pay?  (Amazon-size uniform graph:
         // 129 ms per epoch in row order against 134 longest first; R-MAT of the same size: 118 against 104)
         auto skew = [&](const uint64_t *ptr, uint64_t nnz) {
@@ -899,6 +920,18 @@ int dory_set_option(dory_ctx *c, const char *key, int64_t value) {
         const uint32_t zero = 0;
         HIPCK(c, hipMemcpy(c->sweep_stat + 1, &zero, sizeof(zero), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(c->sweep_stat + 3, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        return DORY_OK;
+    }
+    if (key && !strcmp(key, "spmm_sweep_cus")) {   // workgroups per sweep and XCD of K1s and the GAT sweeps (0: every CU of an XCD).  For several
+        // contexts that SHARE a device (dory_comm_init_local: P ranks on one GPU): each takes its share of the CUs, so that
+        // the ranks' gated sweeps are co-resident beside each other.  Before dory_graph_upload (the layouts are dealt for it).
+        if (c->has_graph) return fail(c, DORY_ERR_ARG, "spmm_sweep_cus: set it before the graph is uploaded");
+        hipDeviceProp_t prop;
+        HIPCK(c, hipGetDeviceProperties(&prop, c->device));
+        const uint32_t all = (uint32_t)std::max(1, prop.multiProcessorCount / 8);
+        if (value < 0 || value > (int64_t)all) return fail(c, DORY_ERR_ARG, "spmm_sweep_cus: 0..%u", all);
+        c->cus_per_xcd = value == 0 ? all : (uint32_t)value;
+        c->opt[key] = value;
         return DORY_OK;
     }
     if (!key || c->opt.find(key) == c->opt.end()) return fail(c, DORY_ERR_ARG, "unknown option '%s'", key ? key : "(null)");

@@ -356,8 +356,12 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 const BlockedAdj &Sf = c->swpIn;
                 const int shl = gatmh_sweep_hl(K, D, z->ld);
                 Tensor *op = find(c, fl, "op"), *dpos = find(c, fl, "dpos");
+                // (the same addressing test the launchers make -- 32-bit byte offsets through the buffer resource -- so that a
+                // partition they would refuse takes the blocked kernels instead of failing, as spmm() does)
+                SpmmArgs sa{};
+                sa.N = c->N; sa.ld = z->ld;
                 const bool sweep = c->opt["gatmh_sweep"] && c->opt["spmm_variant"] == 2 && c->swpIn_built && !c->swpIn_na && Sf.nb > 0 &&
-                                   shl != 0 && op && dpos;
+                                   shl != 0 && op && dpos && sweep_supported(sa, Sf, z->ld >= 128 ? 32 : 16);
                 if (fl < c->gatmh_fwd_swept.size()) c->gatmh_fwd_swept[fl] = 0;
                 if (sweep) {
                     // K1s's skeleton: sums in registers over all source blocks, single-pass softmax against the upper-bound shift
@@ -377,14 +381,14 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                     HIPCK(c, launch_gatmh_sweep_begin(c->N, c->Gsrc, K, z->ld, el->ld, Sf, el->d, fgel->d, c->scratch, c->compute));
                     if (two) {
                         HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, op->d, c->scratch, G, 0,
-                                                                 Sf.nb_local, false, done, ctl, sflags, c->compute));
+                                                                 Sf.nb_local, false, done, ctl, sflags, c->compute, el->d, fgel->d));
                         if ((src_ = wait_halo(c))) return src_;
                         HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, fgz->d, er->d, a_l, o->d, op->d, c->scratch, G,
-                                                                 Sf.nb_local, Sf.nb, true, done, ctl, sflags, c->compute));
+                                                                 Sf.nb_local, Sf.nb, true, done, ctl, sflags, c->compute, el->d, fgel->d));
                     } else {
                         if ((src_ = wait_halo(c))) return src_;
                         HIPCK(c, launch_gatmh_forward_sweep_part(c->N, K, D, z->ld, el->ld, Sf, z->d, c->Gsrc ? fgz->d : nullptr, er->d, a_l, o->d,
-                                                                 op->d, c->scratch, G, 0, Sf.nb, false, done, ctl, sflags, c->compute));
+                                                                 op->d, c->scratch, G, 0, Sf.nb, false, done, ctl, sflags, c->compute, el->d, fgel->d));
                     }
                     HIPCK(c, launch_gatmh_forward_sweep_finish(c->N, K, D, z->ld, el->ld, c->colPtr, c->rowIdx, Sf, z->d, fgz->d, el->d, fgel->d,
                                                                er->d, o->d, op->d, m->d, den->d, dpos->d, c->scratch, c->compute));
@@ -443,8 +447,11 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         const bool dst_rowwise = c->opt["gatmh_sweep"] && shl && op && dpos && fl < c->gatmh_fwd_swept.size() && c->gatmh_fwd_swept[fl] &&
                                  ((z->ld >> 2) % (uint32_t)shl) == 0;
         const BlockedAdj &So = c->swpOut;
+        SpmmArgs sa{};     // the launchers' addressing tests (rows and the 16-byte statistics records through buffer resources): a
+        sa.N = c->N; sa.ld = z->ld;   // partition they would refuse takes the blocked kernels
         const bool src_sweep = c->opt["gatmh_sweep"] && c->opt["spmm_variant"] == 2 && shl && c->swpOut_built && !c->swpOut_na && So.nb > 0 &&
-                               ((z->ld >> 2) % (uint32_t)shl) == 0;
+                               ((z->ld >> 2) % (uint32_t)shl) == 0 && sweep_supported(sa, So, z->ld >= 128 ? 32 : 16) &&
+                               (uint64_t)std::max(c->N, c->Gdst) * K * 16u < (1ull << 32) && K * 16u < (1u << 24);
         if (dst_rowwise && src_sweep) {
             float4 *st4 = reinterpret_cast<float4 *>(st->d);
             const uint32_t lds4 = st->ld / 4;

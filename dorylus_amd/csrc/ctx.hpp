@@ -410,7 +410,7 @@ hipError_t launch_gatmh_sweep_begin(uint32_t N, uint32_t G, uint32_t K, uint32_t
 hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const BlockedAdj &S,
                                            const float *z, const float *zg, const float *er, const float *a_l, float *o, float *op,
                                            float *scratch, uint32_t cus, uint32_t b_lo, uint32_t b_hi, bool accumulate, uint32_t *done,
-                                           const SweepCtl &ctl, uint32_t flags, hipStream_t s);
+                                           const SweepCtl &ctl, uint32_t flags, hipStream_t s, const float *el, const float *elg /* the sources' scores (local, ghost rows) */);
 hipError_t launch_gatmh_forward_sweep_finish(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const uint64_t *colptr,
                                              const uint32_t *rowidx, const BlockedAdj &S, const float *z, const float *zg, const float *el,
                                              const float *elg, const float *er, float *o, float *op, float *m, float *den, float *dpos,

@@ -34,7 +34,7 @@ namespace dory {
 #define GATMH_SRC16_LOADER true
 #endif
 #ifndef GATMH_SRC16_BATCH
-#define GATMH_SRC16_BATCH 2
+#define GATMH_SRC16_BATCH 4   // (round 6, with one statistics gather per batch: 2 -> 4 = 2.91 -> 2.77 ms; 2 was best while every entry had its own)
 #endif
 #ifndef GATMH_FWD16_ROWS
 #define GATMH_FWD16_ROWS 2
@@ -44,6 +44,24 @@ namespace dory {
 #endif
 #ifndef GATMH_FWD16_BATCH
 #define GATMH_FWD16_BATCH SWEEP_U
+#endif
+// forward: the source's score el[u,k] -- 0: formed from the gathered row (<z_u, a_l>: two packed multiplies, an add and log2(HL)
+// DPP adds per entry); 1: fetched from the el table, one 4-byte gather per batch of entries (lane j of a quad fetches entry j's,
+// DPP quad broadcast) -- the same batching as GATMH_SRC_AUX_MODE 3
+// Measured (round 6): 128-float launch 4.04 -> 4.91 ms with the table (the extra gather and its LDS index read cost more than
+// the five vector instructions they replace: the forward is not bound by its arithmetic), 64-float launch 2.51 -> 2.46 ms.
+// Value = the widest lane group that uses the table: 16 = the 64-float launches only.
+#ifndef GATMH_FWD_EL_TABLE
+#define GATMH_FWD_EL_TABLE 16
+#endif
+// rows per 32-lane group: 4 (eight sweeps per XCD at Reddit size), or 6 with batches of two (five sweeps; the only wider form
+// hipcc allocates without spills: 8 rows spill 18-32 registers at any batch size -- the ten accumulator registers per row are
+// the limit, the per-(row, head) constants already sit in the LDS table)
+#ifndef GATMH_FWD_ROWS32
+#define GATMH_FWD_ROWS32 4
+#endif
+#ifndef GATMH_SRC_ROWS32
+#define GATMH_SRC_ROWS32 4
 #endif
 #ifndef GATMH_SRC16_ROWS
 #define GATMH_SRC16_ROWS 2
@@ -56,8 +74,14 @@ namespace dory {
 //   1  only the first lane of each quad (of each pair when a head spans two lanes) loads it, under the EXEC mask; the
 //      others get it by a DPP quad broadcast
 //   2  as 1 without an EXEC change: the other lanes' offsets are out of range (the buffer resource answers zeros)
+//   3  ONE instruction per batch of entries instead of one per entry: the addresser's cost is per instruction
+//      (tools/probes/aux_gather_probe.hip: forms 1 and 2 buy nothing), so lane j of a quad fetches the record of the batch's
+//      entry j and the quad's lanes get entry u's record by a DPP quad broadcast (heads of two lanes: two entries per instruction)
+// Measured (round 6, Reddit-large, 8 heads; profiles/r06_gatmh_aux_forms.txt): 32-lane launch 4.96 (0) / 5.25 (1) / 5.09 (2) /
+// 4.87 ms (3); 16-lane launch with batches of four 2.91 -> 2.77 ms (3).  The probe's 30 % (one gather instruction in four gone)
+// does not arrive in the sweep: its steps are bound by the chain LDS -> gathers -> sums of 16 waves, not by the addresser alone.
 #ifndef GATMH_SRC_AUX_MODE
-#define GATMH_SRC_AUX_MODE 0
+#define GATMH_SRC_AUX_MODE 3
 #endif
 constexpr float GATMH_LOG2E = 1.4426950408889634f;
 constexpr float GATMH_DEN_TINY = 1e-30f;
@@ -103,8 +127,9 @@ __global__ __launch_bounds__(256) void gatmh_elmax_kernel(uint32_t N, uint32_t G
 // of both (self edge, normalisation: finish kernel) ----------------------------------------------------------------------
 template <int GROUP, int HL, int R>
 struct GatFwdSweepOp {
-    static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
-    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : GATMH_FWD_BATCH;
+    static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = (GROUP <= GATMH_FWD_EL_TABLE);
+    static constexpr int EPL = HL >= 4 ? 4 : 2;
+    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : (R >= 6 ? 2 : GATMH_FWD_BATCH);
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;                     // heads per slab of GROUP lanes
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
@@ -115,20 +140,41 @@ struct GatFwdSweepOp {
     float *dacc;        // [N][2 ldk]: unnormalised (den, dpos) pairs (the finish kernel adds the self edge, writes den / dpos)
     float *pos_slots, *den_slots;   // the same for pieces of split rows: [nslots][ld], [nslots][2 ldk]
     uint32_t K, D, ldk;
+    const float *el, *elg;          // GATMH_FWD_EL_TABLE: the sources' scores (local rows, ghost rows)
     // per thread
     float4 al4;
-    uint32_t k, hl;
+    uint32_t k, hl, aux_b, qpos;
+    __amdgpu_buffer_rsrc_t rs2;
     const float2 *ctab;
     typedef float f2 __attribute__((ext_vector_type(2)));
     struct Row { float4 acc, accp; f2 den; };                  // den = (all edges, positive-branch edges)
     struct RowC { float c1, c2; };
-    typedef uint32_t Aux;
-    __device__ __forceinline__ Aux aux(uint32_t, uint32_t, bool) const { return 0u; }
-    template <int NB> __device__ __forceinline__ void aux_batch(const uint2 *, uint32_t, Aux (&)[NB]) const {}
+    typedef float Aux;                                          // AUX_BATCH: el[src, k]
+    __device__ __forceinline__ Aux aux(uint32_t, uint32_t, bool) const { return 0.f; }
+    template <int U0, int NB, int NL>
+    __device__ __forceinline__ void aux_spread(const float (&rec)[NL], Aux (&ax)[NB]) const {
+        if constexpr (U0 < NB) {
+            constexpr int pp = U0 % EPL;
+            constexpr int QP = HL >= 4 ? pp * 0x55 : (pp | (pp << 2) | ((2 + pp) << 4) | ((2 + pp) << 6));
+            ax[U0] = sw_dpp<QP>(rec[U0 / EPL]);
+            aux_spread<U0 + 1, NB, NL>(rec, ax);
+        }
+    }
+    template <int NB> __device__ __forceinline__ void aux_batch(const uint2 *stp, uint32_t n, Aux (&ax)[NB]) const {
+        constexpr int NL = (NB + EPL - 1) / EPL;
+        float rec[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t j = (uint32_t)i * EPL + qpos;
+            const uint32_t sidx = stp[j < (uint32_t)NB ? j : (uint32_t)NB - 1].x;
+            rec[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, j < n ? __umul24(sidx, ldk * 4u) + aux_b : 0xFFFFFFFFu, 0, 0));
+        }
+        aux_spread<0, NB, NL>(rec, ax);
+    }
     __device__ __forceinline__ void init(Row &r) const {
         r.acc = make_float4(0.f, 0.f, 0.f, 0.f); r.accp = r.acc; r.den = (f2){0.f, 0.f};
     }
-    __device__ __forceinline__ void prologue(const SpmmArgs &a, const BlockedAdj &B, uint32_t pos0, uint32_t xend, bool, uint32_t col, int li) {
+    __device__ __forceinline__ void prologue(const SpmmArgs &a, const BlockedAdj &B, uint32_t pos0, uint32_t xend, bool ghost_launch, uint32_t col, int li) {
         __shared__ float2 tab[RW * HPS];
         const uint32_t head0 = (col / GROUP) * HPS;            // first head of this slab
         for (uint32_t i = threadIdx.x; i < (uint32_t)(RW * HPS); i += SWEEP_NT) {
@@ -145,6 +191,11 @@ struct GatFwdSweepOp {
         ctab = tab;
         hl = (uint32_t)li / HL;
         k = min(head0 + hl, K - 1);
+        if constexpr (AUX_BATCH) {
+            rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ghost_launch ? elg : el), 0, (ghost_launch ? B.nghost : a.N) * ldk * 4u, 0x00020000);
+            aux_b = k * 4u - (ghost_launch ? a.N : 0u) * ldk * 4u;
+            qpos = (uint32_t)li & (HL >= 4 ? 3u : 1u);
+        }
         const uint32_t f0 = col * 4, KD = K * D;               // a_l is a dense K x D vector (41-feature heads end mid-float4)
         al4 = make_float4(f0 < KD ? a_l[f0] * GATMH_LOG2E : 0.f, f0 + 1 < KD ? a_l[f0 + 1] * GATMH_LOG2E : 0.f,
                           f0 + 2 < KD ? a_l[f0 + 2] * GATMH_LOG2E : 0.f, f0 + 3 < KD ? a_l[f0 + 3] * GATMH_LOG2E : 0.f);
@@ -157,11 +208,19 @@ struct GatFwdSweepOp {
     // first cut: 3.78 ms per 128-float launch whatever the rows per group or the gates; 13 with the packed forms: 3.39 ms):
     // everything here is written for the packed fp32 instructions (v_pk_mul / v_pk_fma: two lanes' worth per issue slot).
     template <bool FULL>
-    __device__ __forceinline__ void entry(Row &r, const RowC &c, const float4 &x, Aux, bool on) const {
-        const f2 xlo = {x.x, x.y}, xhi = {x.z, x.w}, alo = {al4.x, al4.y}, ahi = {al4.z, al4.w};
-        const f2 p = __builtin_elementwise_fma(xhi, ahi, xlo * alo);                 // v_pk_mul + v_pk_fma
-        const float e = sw_head_sum<HL>(p.x + p.y);                                   // el'[src] of this lane's head
-        const f2 ee = {e, e}, kk = {1.f, GATMH_SLOPE}, cc = {c.c1, c.c2};
+    __device__ __forceinline__ void entry(Row &r, const RowC &c, const float4 &x, Aux ax, bool on) const {
+        float e;
+        f2 kk;
+        if constexpr (AUX_BATCH) {
+            e = ax;                                                                   // el[src] as the scores kernel wrote it
+            kk = (f2){GATMH_LOG2E, GATMH_SLOPE * GATMH_LOG2E};
+        } else {
+            const f2 xlo = {x.x, x.y}, xhi = {x.z, x.w}, alo = {al4.x, al4.y}, ahi = {al4.z, al4.w};
+            const f2 p = __builtin_elementwise_fma(xhi, ahi, xlo * alo);             // v_pk_mul + v_pk_fma
+            e = sw_head_sum<HL>(p.x + p.y);                                           // el'[src] of this lane's head
+            kk = (f2){1.f, GATMH_SLOPE};
+        }
+        const f2 ee = {e, e}, cc = {c.c1, c.c2};
         const f2 t = __builtin_elementwise_fma(ee, kk, cc);                            // (e + c1, 0.2 e + c2): one v_pk_fma
         float al = __builtin_amdgcn_exp2f(fmaxf(t.x, t.y));
         if constexpr (!FULL) al = on ? al : 0.f;               // (an absent slot gathered zeros: its score is not zero)
@@ -196,8 +255,8 @@ template <int GROUP, int HL, int R, bool LOADER>
 __global__ __launch_bounds__(SWEEP_NT) void gatmh_forward_sweep_kernel(SpmmArgs a, BlockedAdj B, SweepArgs w, const float *er,
                                                                        const float *a_l, const int *elmax_key, float *accp, float *dacc,
                                                                        float *pos_slots, float *den_slots, uint32_t K, uint32_t D,
-                                                                       uint32_t ldk) {
-    GatFwdSweepOp<GROUP, HL, R> op{er, a_l, elmax_key, accp, dacc, pos_slots, den_slots, K, D, ldk};
+                                                                       uint32_t ldk, const float *el, const float *elg) {
+    GatFwdSweepOp<GROUP, HL, R> op{er, a_l, elmax_key, accp, dacc, pos_slots, den_slots, K, D, ldk, el, elg};
     sweep_run<GROUP, R, false, LOADER>(a, B, w, op);
 }
 
@@ -333,8 +392,9 @@ template <int GROUP, int HL, int R>
 struct GatSrcSweepOp {
     // (the destinations' statistics fetched once per batch through the LDS crossbar instead of once per entry: measured, no gain --
     // profiles/r05_gatmh_src_aux_batch_experiment.patch)
-    static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = false;
-    static constexpr int BATCH = GROUP == 16 ? GATMH_SRC16_BATCH : GATMH_SRC_BATCH;   // two gathers per entry (rows, statistics); 16-lane groups: four lane groups per gather instruction
+    static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = GATMH_SRC_AUX_MODE == 3;
+    static constexpr int BATCH = GROUP == 16 ? GATMH_SRC16_BATCH : (R >= 6 ? 2 : GATMH_SRC_BATCH);   // two gathers per entry (rows, statistics); 16-lane groups: four lane groups per gather instruction
+    static constexpr int EPL = HL >= 4 ? 4 : 2;    // AUX_BATCH: entries one statistics gather serves (the lanes of a quad that share a head)
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
@@ -346,7 +406,7 @@ struct GatSrcSweepOp {
     float *pos_slots, *t_slots;     // pieces of split rows
     uint32_t K, D, ldk, N, G;
     // per thread
-    uint32_t k, hl, aux_b;
+    uint32_t k, hl, aux_b, qpos;
     bool aux_leader;
     __amdgpu_buffer_rsrc_t rs2;
     const float2 *etab;
@@ -378,6 +438,7 @@ struct GatSrcSweepOp {
         rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(ghost_launch ? stxg : stx), 0, (ghost_launch ? G : N) * rowb, 0x00020000);
         aux_b = k * 16u - (ghost_launch ? N : 0u) * rowb;
         aux_leader = ((uint32_t)li & (HL >= 4 ? 3u : 1u)) == 0u;
+        qpos = (uint32_t)li & (HL >= 4 ? 3u : 1u);
     }
     __device__ __forceinline__ RowC row_const(uint32_t lrow) const {
         const float2 c = etab[lrow * HPS + hl];
@@ -395,10 +456,33 @@ struct GatSrcSweepOp {
 #endif
         return make_float3(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z));
     }
-    template <int NB> __device__ __forceinline__ void aux_batch(const uint2 *, uint32_t, Aux (&)[NB]) const {}
+    // AUX_BATCH: the records of the batch's entries [0, n) -- lane (quad position j) fetches entry i * EPL + j with load i
+    template <int U0, int NB, int NL>
+    __device__ __forceinline__ void aux_spread(const float3 (&rec)[NL], Aux (&ax)[NB]) const {
+        if constexpr (U0 < NB) {
+            constexpr int pp = U0 % EPL;
+            constexpr int QP = HL >= 4 ? pp * 0x55 : (pp | (pp << 2) | ((2 + pp) << 4) | ((2 + pp) << 6));
+            const float3 &v = rec[U0 / EPL];
+            ax[U0] = make_float3(sw_dpp<QP>(v.x), sw_dpp<QP>(v.y), sw_dpp<QP>(v.z));
+            aux_spread<U0 + 1, NB, NL>(rec, ax);
+        }
+    }
+    template <int NB> __device__ __forceinline__ void aux_batch(const uint2 *stp, uint32_t n, Aux (&ax)[NB]) const {
+        typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+        constexpr int NL = (NB + EPL - 1) / EPL;
+        float3 rec[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t j = (uint32_t)i * EPL + qpos;
+            const uint32_t sidx = stp[j < (uint32_t)NB ? j : (uint32_t)NB - 1].x;       // (one LDS read per lane: four addresses per head)
+            const u3 v = __builtin_amdgcn_raw_buffer_load_b96(rs2, j < n ? __umul24(sidx, K * 16u) + aux_b : 0xFFFFFFFFu, 0, 0);
+            rec[i] = make_float3(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z));
+        }
+        aux_spread<0, NB, NL>(rec, ax);
+    }
     template <bool FULL>
     __device__ __forceinline__ void entry(Row &r, const RowC &c, const float4 &x, const Aux &sv0, bool on) const {
-#if GATMH_SRC_AUX_MODE != 0
+#if GATMH_SRC_AUX_MODE == 1 || GATMH_SRC_AUX_MODE == 2
         // the record sits in the first lane of the quad (HL >= 4) or of the pair (HL == 2): quad_perm [0,0,0,0] / [0,0,2,2]
         constexpr int QP = HL >= 4 ? 0x00 : 0xA0;
         const Aux sv = make_float3(sw_dpp<QP>(sv0.x), sw_dpp<QP>(sv0.y), sw_dpp<QP>(sv0.z));
@@ -509,9 +593,10 @@ int gatmh_sweep_rows(const BlockedAdj &S, int group, int HL, int pass) {
     // same rows per workgroup and step as the layout was dealt for.  Measured (round 5, Reddit-large, 8 heads, loader wave on):
     // forward 2 / 4 rows = 2.50 / 2.77 ms, source side 2 / 4 / 6 rows = 2.91 / 3.01 / 3.50 ms
     if (group == 16) return std::max(2, std::min(r / 2, pass == 0 ? GATMH_FWD16_ROWS : GATMH_SRC16_ROWS));
-    const int cap = pass == 0 ? 4 : (HL != 16 ? 4 : 2);   // ten registers per row; the source side keeps two gathers per entry in flight
+    const int cap = pass == 0 ? GATMH_FWD_ROWS32 : (HL != 16 ? GATMH_SRC_ROWS32 : 2);   // ten registers per row; the source side keeps two gathers per entry in flight
     int R = std::min(r, cap);
     if (R == 3) R = 2;
+    if (R == 5) R = 4;
     return R;
 }
 
@@ -582,7 +667,7 @@ static bool gatmh_sweep_geom(const SpmmArgs &a, const BlockedAdj &S, int group, 
 hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, uint32_t ld, uint32_t ldk, const BlockedAdj &S,
                                            const float *z, const float *zg, const float *er, const float *a_l, float *o, float *op,
                                            float *scratch, uint32_t cus, uint32_t b_lo, uint32_t b_hi, bool accumulate, uint32_t *done,
-                                           const SweepCtl &ctl, uint32_t flags, hipStream_t s) {
+                                           const SweepCtl &ctl, uint32_t flags, hipStream_t s, const float *el, const float *elg) {
     if (N == 0 || b_lo >= b_hi) return hipSuccess;
     const int group = ld >= 128 ? 32 : 16;
     const int HL = gatmh_sweep_hl(K, D, ld);
@@ -596,11 +681,15 @@ hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, u
     hipError_t e = hipMemsetAsync(done, 0, ((size_t)8 * w.nsweeps * (b_hi - b_lo) * 32 + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const dim3 bl(SWEEP_NT);
-#define GFS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_forward_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, er, a_l, c.keys, op, c.dacc, c.pos_slots, c.den_slots, K, D, ldk)
+#define GFS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_forward_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, er, a_l, c.keys, op, c.dacc, c.pos_slots, c.den_slots, K, D, ldk, el, elg)
+#if GATMH_FWD_ROWS32 >= 6
+#define GFS_R(HLV) do { if (R == 6) GFS(32, HLV, 6, true); else if (R == 4) GFS(32, HLV, 4, true); else GFS(32, HLV, 2, true); } while (0)
+#else
 #define GFS_R(HLV) do { if (R == 4) GFS(32, HLV, 4, true); else GFS(32, HLV, 2, true); } while (0)
+#endif
 #define GFS_R16(HLV) do { if (R == 4) GFS(16, HLV, 4, true); else GFS(16, HLV, 2, true); } while (0)
     if (group == 32) {
-        if (R > 4) return hipErrorInvalidValue;
+        if (R > GATMH_FWD_ROWS32) return hipErrorInvalidValue;
         if (HL == 2) GFS_R(2); else if (HL == 4) GFS_R(4); else if (HL == 8) GFS_R(8); else GFS_R(16);
     } else {
         if (R > 4) return hipErrorInvalidValue;
@@ -697,8 +786,12 @@ hipError_t launch_gatmh_src_sweep_part(uint32_t N, uint32_t G, uint32_t K, uint3
     const dim3 bl(SWEEP_NT);
 #define GSS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_src_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, el, c.stx, c.stxg, c.sp, c.tacc, c.pos_slots, c.t_slots, K, D, ldk, G)
     if (group == 32) {
-        if (R != 2 && R != 4) return hipErrorInvalidValue;
+        if (R != 2 && R != 4 && R != GATMH_SRC_ROWS32) return hipErrorInvalidValue;
+#if GATMH_SRC_ROWS32 >= 6
+#define GSS_R(HLV) do { if (R == 6) GSS(32, HLV, 6, true); else if (R == 4) GSS(32, HLV, 4, true); else GSS(32, HLV, 2, true); } while (0)
+#else
 #define GSS_R(HLV) do { if (R == 4) GSS(32, HLV, 4, true); else GSS(32, HLV, 2, true); } while (0)
+#endif
         if (HL == 2) GSS_R(2); else if (HL == 4) GSS_R(4); else if (HL == 8) GSS_R(8); else GSS_R(16);
 #undef GSS_R
     } else {

@@ -172,12 +172,14 @@ static int labelstobinary(int argc, char **argv) {
 static int partitioner(int argc, char **argv) {
     std::vector<std::string> pos;
     std::string method = "block";
+    int passes = 3;
     for (int i = 1; i < argc; ++i) {
         if (!strncmp("--method=", argv[i], 9)) method = argv[i] + 9;
+        else if (!strncmp("--passes=", argv[i], 9)) passes = std::max(1, atoi(argv[i] + 9));   // ldg: restreaming passes
         else pos.push_back(argv[i]);
     }
     if (pos.size() != 3) {
-        std::cout << "Usage: partitioner <GraphBsnapFile> <NumVertices> <NumPartitions> [--method=block|hash|bfs|ldg]" << std::endl;
+        std::cout << "Usage: partitioner <GraphBsnapFile> <NumVertices> <NumPartitions> [--method=block|hash|bfs|ldg] [--passes=N]" << std::endl;
         return -1;
     }
     const std::string graph = pos[0];
@@ -251,7 +253,7 @@ static int partitioner(int argc, char **argv) {
         std::vector<int> where(V, -1);
         std::vector<unsigned> size(P, 0);
         std::vector<unsigned> hits(P, 0);
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int pass = 0; pass < passes; ++pass) {
             for (unsigned v = 0; v < V; ++v) {
                 if (where[v] >= 0) --size[where[v]];
                 std::fill(hits.begin(), hits.end(), 0u);

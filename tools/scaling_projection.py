@@ -76,8 +76,9 @@ def project(ranks, dims, P):
             "model": {"link_GBps": LINK_GBPS, "pack_unpack_GBps": HBM_EFF_GBPS, "exchange_latency_ms": LAT_MS, "allreduce_hop_ms": AR_HOP_MS}}
 
 
-def measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, steps, warmup):
-    parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
+def measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, steps, warmup, parts=None):
+    if parts is None:
+        parts = (np.arange(V, dtype=np.int64) * P // V).astype(np.int32)
     if src is None:   # configs 4 / 5: only the records incident to the rank's block
         s_, d_ = bench.synth_incident_edges(V, bench.WORKLOADS[workload][1], r, P)
         part = da.Partition.build(s_, d_, parts, r, P)
@@ -135,18 +136,29 @@ def main():
     import dorylus_amd as da
     out = {"what": __doc__.split("\n\n")[0], "cases": {}}
     for case in a.cases:
-        workload, graph = case.split(":")
+        # <workload>:<graph>[:<partitioning>] -- a partitioning names build/parts/<workload>_<graph>_<partitioning>.npy, written by
+        # tools/make_partitions.py for the id-SHUFFLED community graph of that size (round 6, review item 3); without it:
+        # contiguous blocks, as bench.py partitions
+        workload, graph, *pname = case.split(":")
         V, E, dims = bench.WORKLOADS[workload]
         src = dst = None
-        if workload == "reddit":
+        parts_vec = None
+        if pname:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import make_partitions as mp
+            src, dst = mp.community_edges(V, E, 50, 0.85)
+            src, dst, _ = mp.shuffled(V, src, dst)
+            parts_vec = np.load(os.path.join(ROOT, "build", "parts", f"{workload}_{graph}_{pname[0]}.npy")).astype(np.int32)
+        elif workload == "reddit":
             src, dst = bench.synth_edges(graph, V, E)
-        res = {"workload": workload, "graph": graph, "vertices": V, "dims": dims, "by_P": {}}
+        res = {"workload": workload, "graph": graph + (" (ids shuffled)" if pname else ""), "partitioning": pname[0] if pname else "contiguous blocks",
+               "vertices": V, "dims": dims, "by_P": {}}
         # P = 1 for reference (Reddit only: the whole Amazon graph on one GPU is bench.py --workload amazon)
         if workload == "reddit":
             r1 = measure_rank(da, bench, workload, graph, src, dst, V, dims, 0, 1, a.steps, a.warmup)
             res["single_gpu_epoch_ms"] = r1["compute_ms"]
         for P in a.P:
-            ranks = [measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, a.steps, a.warmup) for r in range(P)]
+            ranks = [measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, a.steps, a.warmup, parts_vec) for r in range(P)]
             pr = project(ranks, dims, P)
             pr["ranks"] = ranks
             if "single_gpu_epoch_ms" in res:
