@@ -54,15 +54,6 @@ namespace dory {
 #ifndef GATMH_FWD_EL_TABLE
 #define GATMH_FWD_EL_TABLE 16
 #endif
-// rows per 32-lane group: 4 (eight sweeps per XCD at Reddit size), or 6 with batches of two (five sweeps; the only wider form
-// hipcc allocates without spills: 8 rows spill 18-32 registers at any batch size -- the ten accumulator registers per row are
-// the limit, the per-(row, head) constants already sit in the LDS table)
-#ifndef GATMH_FWD_ROWS32
-#define GATMH_FWD_ROWS32 4
-#endif
-#ifndef GATMH_SRC_ROWS32
-#define GATMH_SRC_ROWS32 4
-#endif
 #ifndef GATMH_SRC16_ROWS
 #define GATMH_SRC16_ROWS 2
 #endif
@@ -129,7 +120,7 @@ template <int GROUP, int HL, int R>
 struct GatFwdSweepOp {
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = (GROUP <= GATMH_FWD_EL_TABLE);
     static constexpr int EPL = HL >= 4 ? 4 : 2;
-    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : (R >= 6 ? 2 : GATMH_FWD_BATCH);
+    static constexpr int BATCH = GROUP == 16 ? GATMH_FWD16_BATCH : GATMH_FWD_BATCH;
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;                     // heads per slab of GROUP lanes
     static constexpr int RW = (SWEEP_NT / GROUP) * R;
@@ -393,7 +384,7 @@ struct GatSrcSweepOp {
     // (the destinations' statistics fetched once per batch through the LDS crossbar instead of once per entry: measured, no gain --
     // profiles/r05_gatmh_src_aux_batch_experiment.patch)
     static constexpr bool PLAIN = false, UNIT_W = true, PROLOGUE = true, AUX_BATCH = GATMH_SRC_AUX_MODE == 3;
-    static constexpr int BATCH = GROUP == 16 ? GATMH_SRC16_BATCH : (R >= 6 ? 2 : GATMH_SRC_BATCH);   // two gathers per entry (rows, statistics); 16-lane groups: four lane groups per gather instruction
+    static constexpr int BATCH = GROUP == 16 ? GATMH_SRC16_BATCH : GATMH_SRC_BATCH;   // two gathers per entry (rows, statistics); 16-lane groups: four lane groups per gather instruction
     static constexpr int EPL = HL >= 4 ? 4 : 2;    // AUX_BATCH: entries one statistics gather serves (the lanes of a quad that share a head)
     static constexpr int SLACK = GATMH_SLACK;
     static constexpr int HPS = GROUP / HL;
@@ -593,10 +584,13 @@ int gatmh_sweep_rows(const BlockedAdj &S, int group, int HL, int pass) {
     // same rows per workgroup and step as the layout was dealt for.  Measured (round 5, Reddit-large, 8 heads, loader wave on):
     // forward 2 / 4 rows = 2.50 / 2.77 ms, source side 2 / 4 / 6 rows = 2.91 / 3.01 / 3.50 ms
     if (group == 16) return std::max(2, std::min(r / 2, pass == 0 ? GATMH_FWD16_ROWS : GATMH_SRC16_ROWS));
-    const int cap = pass == 0 ? GATMH_FWD_ROWS32 : (HL != 16 ? GATMH_SRC_ROWS32 : 2);   // ten registers per row; the source side keeps two gathers per entry in flight
+    // ten accumulator registers per row (the per-(row, head) constants already sit in the LDS table): 4 rows are what fits 128
+    // registers with batches of 3-4.  Round 6 (profiles/r06_gatmh_aux_forms.txt): 6 rows fit without spills only with batches of
+    // two (five sweeps per XCD instead of eight) and run the 128-float forward at 4.77 instead of 4.09 ms; 8 rows spill 18-32
+    // registers at any batch size
+    const int cap = pass == 0 ? 4 : (HL != 16 ? 4 : 2);
     int R = std::min(r, cap);
     if (R == 3) R = 2;
-    if (R == 5) R = 4;
     return R;
 }
 
@@ -682,14 +676,10 @@ hipError_t launch_gatmh_forward_sweep_part(uint32_t N, uint32_t K, uint32_t D, u
     if (e != hipSuccess) return e;
     const dim3 bl(SWEEP_NT);
 #define GFS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_forward_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, er, a_l, c.keys, op, c.dacc, c.pos_slots, c.den_slots, K, D, ldk, el, elg)
-#if GATMH_FWD_ROWS32 >= 6
-#define GFS_R(HLV) do { if (R == 6) GFS(32, HLV, 6, true); else if (R == 4) GFS(32, HLV, 4, true); else GFS(32, HLV, 2, true); } while (0)
-#else
 #define GFS_R(HLV) do { if (R == 4) GFS(32, HLV, 4, true); else GFS(32, HLV, 2, true); } while (0)
-#endif
 #define GFS_R16(HLV) do { if (R == 4) GFS(16, HLV, 4, true); else GFS(16, HLV, 2, true); } while (0)
     if (group == 32) {
-        if (R > GATMH_FWD_ROWS32) return hipErrorInvalidValue;
+        if (R > 4) return hipErrorInvalidValue;
         if (HL == 2) GFS_R(2); else if (HL == 4) GFS_R(4); else if (HL == 8) GFS_R(8); else GFS_R(16);
     } else {
         if (R > 4) return hipErrorInvalidValue;
@@ -786,12 +776,8 @@ hipError_t launch_gatmh_src_sweep_part(uint32_t N, uint32_t G, uint32_t K, uint3
     const dim3 bl(SWEEP_NT);
 #define GSS(GRP, HLV, RR, LD) hipLaunchKernelGGL((gatmh_src_sweep_kernel<GRP, HLV, RR, LD>), gr, bl, 0, s, a, S, w, el, c.stx, c.stxg, c.sp, c.tacc, c.pos_slots, c.t_slots, K, D, ldk, G)
     if (group == 32) {
-        if (R != 2 && R != 4 && R != GATMH_SRC_ROWS32) return hipErrorInvalidValue;
-#if GATMH_SRC_ROWS32 >= 6
-#define GSS_R(HLV) do { if (R == 6) GSS(32, HLV, 6, true); else if (R == 4) GSS(32, HLV, 4, true); else GSS(32, HLV, 2, true); } while (0)
-#else
+        if (R != 2 && R != 4) return hipErrorInvalidValue;
 #define GSS_R(HLV) do { if (R == 4) GSS(32, HLV, 4, true); else GSS(32, HLV, 2, true); } while (0)
-#endif
         if (HL == 2) GSS_R(2); else if (HL == 4) GSS_R(4); else if (HL == 8) GSS_R(8); else GSS_R(16);
 #undef GSS_R
     } else {

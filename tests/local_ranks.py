@@ -18,7 +18,7 @@ def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, ti
     for r, part in enumerate(parts_objs):
         ctx = da.Context(0)
         ctx.configure(gnn, dims, V, r, P)
-        for k, v in (opts or {}).items():
+        for k, v in ((opts[r] if isinstance(opts, (list, tuple)) else opts) or {}).items():     # one dict for all ranks, or one per rank
             ctx.set_option(k, v)
         part.upload(ctx, parts_vec)          # adjacency + both halo plans (host/partition.cpp)
         ctx.preallocate()

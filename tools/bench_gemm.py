@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--N", type=int, default=232965)
     ap.add_argument("--dims", type=int, nargs=3, default=[602, 128, 41])
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--opt", nargs="*", default=[], help="context options key=value, e.g. gemm_persistent=1")
     a = ap.parse_args()
     N, dims = a.N, a.dims
     ptr = np.arange(N + 1, dtype=np.uint64)            # one edge per vertex: the graph does not matter here
@@ -28,6 +29,9 @@ def main():
              csrVal=val, norm=np.full(N, 0.5, np.float32))
     ctx = da.Context(0)
     ctx.configure(da.GCN, dims, N)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     ctx.graph_upload(g)
     ctx.preallocate()
     ctx.weights_init_xavier()
