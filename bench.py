@@ -201,6 +201,24 @@ def spmm_source_stamp():
     return h.hexdigest()
 
 
+def source_stamp(files):
+    """as spmm_source_stamp, over any set of kernel sources (comments and white space removed)"""
+    import hashlib
+    import re
+    d = os.path.join(ROOT, "dorylus_amd", "csrc")
+    h = hashlib.sha1()
+    for f in files:
+        with open(os.path.join(d, f), "r", encoding="utf-8") as fh:
+            src = fh.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(re.sub(r"\s+", " ", src).encode())
+    return h.hexdigest()
+
+
+GATMH_STAMP_FILES = ("gat_mh_sweep.hip", "sweep_core.hpp")
+
+
 def spmm_algorithmic_bytes(N, G, E, F):
     """compulsory bytes of one SpMM launch."""
     return E * 8 + 8 * (N + 1) + 4 * N + 4 * F * (N + G) + 4 * F * N
@@ -777,14 +795,14 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
         try:     # HBM-side bytes per epoch from the separate --pmc FETCH_SIZE pass (profiles/), for the kernel source it was collected for
             ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(pmc_key or "", None)
             if ent and ent.get("spmm_hip_blob") == spmm_source_stamp():
-                traffic_, traffic_src_ = ent["fetch_bytes_per_epoch"], ent["source"]
+                traffic_, traffic_src_ = ent.get("bytes_per_epoch", ent["fetch_bytes_per_epoch"]), ent["source"]
             elif ent:
                 traffic_src_ = "stale: collected for another spmm.hip -- re-run tools/collect_profiles.sh"
         except (OSError, KeyError, ValueError):
             pass
         res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": traffic_, "traffic_source": traffic_src_,
-                           "traffic_what": "HBM-side FETCH bytes per epoch (all its aggregation launches); algorithmic_bytes_per_epoch is the figure `achieved` uses",
+                           "traffic_what": "HBM-side bytes per epoch (2 x FETCH_SIZE + WRITE_SIZE of all its aggregation launches; FETCH only where no WRITE pass is on record); algorithmic_bytes_per_epoch is the figure `achieved` uses",
                            "kernel": "spmm_rows_kernel<GROUP,CHUNKS> (K1 row gather; %d launches per epoch)" % (2 * nl_ - 1),
                            "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
                            "gathered_bytes_per_epoch": int(gathered), "gathered_TBps": round(gathered / t / 1e12, 3),
@@ -804,8 +822,18 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
             algo += 4 * 4 * N * ld_
         gathered = 4 * (nnz_in + nnz_out) * (lds[0] + lds[1])
         t = fam["spmm"][0] / steps * 1e-3
+        traffic_, traffic_src_ = None, "no PMC pass on record for this build of the sweep kernels"
+        try:     # HBM-side bytes of the epoch's sweep kernels: separate --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_profiles.sh)
+            ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("gatmh_sweeps", None)
+            if ent and swept and ent.get("source_stamp") == source_stamp(GATMH_STAMP_FILES):
+                traffic_, traffic_src_ = ent["bytes_per_epoch"], ent["source"]
+            elif ent:
+                traffic_src_ = "stale: collected for another gat_mh_sweep.hip / sweep_core.hpp -- re-run tools/collect_profiles.sh"
+        except (OSError, KeyError, ValueError):
+            pass
         res["roofline"] = {"bound": "hbm", "achieved": round(algo / t / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": None,
+                           "frac": round(algo / t / 1e9 / 8000.0, 5), "traffic": traffic_, "traffic_source": traffic_src_,
+                           "traffic_what": "HBM-side bytes per epoch of the four sweep kernels (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                            "algorithmic_bytes_per_epoch": int(algo), "aggregation_ms_per_epoch": round(t * 1e3, 4),
                            "kernel": ("gatmh_forward_sweep_kernel + gatmh_src_sweep_kernel on K1s's skeleton (four edge passes per epoch: single-pass "
                                       "softmax against an upper-bound shift; t / der row-wise from the forward's positive-branch sums)") if swept else

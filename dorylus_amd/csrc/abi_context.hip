@@ -227,6 +227,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["spmm_edge_split"] = 1;        // K1 on GCN partitions with ghosts: every row's local-source edges first (set before dory_graph_upload)
     c->opt["spmm_sweep_cus"] = 0;         // K1s / GAT sweeps: workgroups per sweep and XCD (0 = all CUs of an XCD); see dory_set_option
     c->opt["local_timeout_ms"] = 30000;   // in-process device transport: how long a rank's host thread waits for a peer's host thread
     c->opt["adjacency_values_asymmetric"] = 0;   // set by dory_partition_upload for undirected / unknown builds: csrVal != cscVal^T
@@ -255,6 +256,12 @@ static void free_graph(dory_ctx *c) {
     c->orderIn = c->orderOut = nullptr;
     c->splitIn = c->splitOut = nullptr;
     c->nIntIn = c->nIntOut = 0;
+    for (EdgeSplit *E : {&c->esIn, &c->esOut}) {
+        if (E->idx) (void)hipFree(E->idx);
+        if (E->val) (void)hipFree(E->val);
+        if (E->mid) (void)hipFree(E->mid);
+        *E = EdgeSplit{};
+    }
     for (LongRowsDev *L : {&c->longIn, &c->longOut}) {
         if (L->rows) (void)hipFree(L->rows);
         if (L->row_chunk_ptr) (void)hipFree(L->row_chunk_ptr);
@@ -442,6 +449,30 @@ int dory_graph_upload(dory_ctx *c, uint32_t N, uint32_t Gsrc, uint32_t Gdst, uin
         if ((rc = upload_array(c, &L.rows, h.rows.data(), h.rows.size()))) return rc;
         if ((rc = upload_array(c, &L.row_chunk_ptr, h.row_chunk_ptr.data(), h.row_chunk_ptr.size()))) return rc;
         if ((rc = upload_array(c, &L.chunks, h.chunks.data(), h.chunks.size()))) return rc;
+    }
+    // K1's local-first edge order (ctx.hpp: EdgeSplit) for GCN partitions with ghosts and without hub rows
+    for (int d = 0; d < 2 && c->gnn == DORY_GCN && c->opt["spmm_edge_split"]; ++d) {
+        if ((d == 0 ? Gsrc : Gdst) == 0 || (d == 0 ? c->longIn : c->longOut).nchunks) continue;
+        const uint64_t *ptr = d == 0 ? column_ptrs : row_ptrs;
+        const uint32_t *idx = d == 0 ? row_idxs : column_idxs;
+        const float *val = d == 0 ? csc_values : csr_values;
+        const uint64_t nnz = d == 0 ? nnz_in : nnz_out;
+        std::vector<uint32_t> i2(nnz);
+        std::vector<float> v2(nnz);
+        std::vector<uint64_t> mid(N);
+#pragma omp parallel for schedule(dynamic, 4096)
+        for (int64_t v = 0; v < (int64_t)N; ++v) {
+            uint64_t w = ptr[v];
+            for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e)
+                if (idx[e] < N) { i2[w] = idx[e]; v2[w] = val[e]; ++w; }
+            mid[v] = w;
+            for (uint64_t e = ptr[v]; e < ptr[v + 1]; ++e)
+                if (idx[e] >= N) { i2[w] = idx[e]; v2[w] = val[e]; ++w; }
+        }
+        EdgeSplit &E = d == 0 ? c->esIn : c->esOut;
+        if ((rc = upload_array(c, &E.idx, i2.data(), nnz))) return rc;
+        if ((rc = upload_array(c, &E.val, v2.data(), nnz))) return rc;
+        if ((rc = upload_array(c, &E.mid, mid.data(), (uint64_t)N))) return rc;
     }
     c->has_graph = true;
     return DORY_OK;

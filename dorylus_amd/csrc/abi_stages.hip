@@ -248,10 +248,45 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         if (rc) return rc;
         a.row_clamp = LONG_ROW_CLAMP;
     }
-    // K1 under an exchange in flight: the rows whose sources are all local do not depend on it -- they run first, the
-    // rows that read ghost rows after the comm stream's event (what the local-source blocks are for K1b)
+    // K1 under an exchange in flight.  GCN partitions with ghosts hold a local-first copy of the edges (ctx.hpp: EdgeSplit): one
+    // launch sums every row's local-source edges beside the exchange, a second one goes on from those sums with the ghost-
+    // source edges (boundary rows only) -- the additions happen in the same order as in ONE launch over the copy, which is what
+    // runs when nothing is in flight: overlapped and sequential schedule give the same bits.
     uint32_t *split = csc ? c->splitIn : c->splitOut;
     const uint32_t nInt = csc ? c->nIntIn : c->nIntOut;
+    const EdgeSplit &es = csc ? c->esIn : c->esOut;
+    // (layer 0's forward aggregation reads ghost rows that came from a file: no exchange ever precedes it, in either schedule,
+    // so it keeps the reference's edge order -- the local-first copy costs the 300-float Amazon launch a few per cent)
+    if (es.idx && a.xg && val == (csc ? c->cscVal : c->csrVal) && !longRows.nchunks && !a.accumulate && c->opt["spmm_edge_split"] &&
+        !c->agg_static_ghosts) {
+        a.idx = es.idx;
+        a.val = es.val;
+        Timed t(c, "spmm", c->compute);
+        if (c->halo_pending || c->opt["spmm_blk_force_split"]) {
+            SpmmArgs p1 = a;
+            p1.ptr_end = es.mid;
+            {
+                Timed tb(c, c->halo_pending ? "spmm_beside_halo" : "spmm_local_first", c->compute);
+                HIPCK(c, launch_spmm(p1, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+            }
+            int rc = wait_halo(c);
+            if (rc) return rc;
+            SpmmArgs p2 = a;
+            p2.ptr = es.mid;
+            p2.ptr_end = a.ptr + 1;
+            p2.self_mode = 0;
+            p2.accumulate = 2;
+            if (split && nInt < c->N) { p2.order = split + nInt; p2.rows = c->N - nInt; }   // rows without a ghost source are done
+            if (!split || nInt < c->N) HIPCK(c, launch_spmm(p2, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+            return DORY_OK;
+        }
+        int rc = wait_halo(c);
+        if (rc) return rc;
+        HIPCK(c, launch_spmm(a, (int)c->opt["spmm_variant"], (int)c->opt["spmm_slab"], c->compute));
+        return DORY_OK;
+    }
+    // (other cases -- GAT's per-epoch edge values, hub rows: the rows whose sources are all local run first, the rows that read
+    // ghost rows after the comm stream's event)
     const bool split_rows = (c->halo_pending || c->opt["spmm_blk_force_split"]) && split && nInt > 0 && nInt < c->N &&
                             !longRows.nchunks;
     Timed t(c, "spmm", c->compute);
@@ -312,12 +347,17 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
             // layer 0 is skipped while nothing it reads has been written through this ABI since it was last computed.
             if (layer == 0 && c->opt["gcn_cache_ah0"] && !c->capturing) {
                 if (c->ah0_valid) { c->ah0_skips++; return DORY_OK; }
+                c->agg_static_ghosts = true;
                 int rc = spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+                c->agg_static_ghosts = false;
                 c->ah0_valid = rc == DORY_OK;
                 return rc;
             }
             if (layer == 0) c->ah0_valid = false;
-            return spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+            c->agg_static_ghosts = layer == 0;
+            const int src_ = spmm(c, true, c->cscVal, 1, *in, fg, *ah, c->dims[layer], 0);
+            c->agg_static_ghosts = false;
+            return src_;
         }
         if (tf_layer(c, layer)) {   // u_l = A^T g_l (ghost rows of g_l: backward exchange of layer l); dW_l = in_l^T u_l
             NEED(g, layer, "g"); NEED(bgg, layer, "bgg"); NEED(u, layer, "u");

@@ -80,6 +80,15 @@ struct LongRowsHost {                    // plan_long_rows output
     std::vector<uint32_t> row_chunk_ptr; // rows+1: first chunk of each
     std::vector<uint32_t> chunks;        // 6 words per chunk: row, 0, e0 (lo, hi), e1 (lo, hi)  (= struct LongChunk)
 };
+// K1 beside an exchange in flight (round 6): every row's edges regrouped local sources first, ghost sources after (stable), so
+// that ONE pass over all rows sums the local part while the ghost rows are still travelling and a second pass adds the rest --
+// the row gather's counterpart of K1s's local-source blocks.  The interior / boundary ROW split it replaces hides nothing on
+// a graph where nearly every row has a ghost neighbour (mean degree 25, 15 % remote edges: 98 % of the rows).
+struct EdgeSplit {
+    uint32_t *idx = nullptr;   // nnz: source ids, local ones first within every row
+    float *val = nullptr;      // nnz
+    uint64_t *mid = nullptr;   // N: first ghost-source edge of the row
+};
 struct LongRowsDev {
     uint32_t nrows = 0, nchunks = 0;
     uint32_t *rows = nullptr, *row_chunk_ptr = nullptr, *chunks = nullptr;
@@ -130,6 +139,8 @@ struct dory_ctx {
     uint32_t *splitIn = nullptr, *splitOut = nullptr;   // N entries: interior rows, then boundary rows
     uint32_t nIntIn = 0, nIntOut = 0;
     dory::LongRowsDev longIn, longOut;          // K1: hub rows of forwardAdj / backwardAdj
+    bool agg_static_ghosts = false;             // the aggregation being issued reads ghost rows no exchange writes (layer 0 forward)
+    dory::EdgeSplit esIn, esOut;                // K1: local-first copies of forwardAdj / backwardAdj (GCN partitions with ghosts)
     // K1b blocked copies of forwardAdj / backwardAdj (built on first use) + partial buffer
     dory::BlockedAdj blkIn, blkOut;
     // multi-head GAT contexts with layers on both sides of 128 floats: a second pair, blocked for the 256-B slabs of the narrow
@@ -247,6 +258,7 @@ struct SpmmArgs {
     uint32_t row_clamp;     // K1: edges of a row beyond this many are left to the long-row kernels (0 = no limit)
     uint32_t rows;          // K1: rows of this launch = the first `rows` entries of `order` (0 = all N rows)
     const uint32_t *order;  // optional row schedule (longest first) or nullptr
+    const uint64_t *ptr_end;// K1: end of every row's edge range (nullptr: ptr[v + 1]); with accumulate == 2 the sum STARTS from out[v]
 };
 hipError_t launch_spmm(const SpmmArgs &a, int variant, int slab, hipStream_t s);
 

@@ -20,6 +20,11 @@
 // kernel.  The source-side sweep uses the same split: del[u,k] = <Z[u,k,:], 0.2 S + 0.8 S+> - (0.2 T + 0.8 T+) with
 // S = sum_v alpha dO_v (the main term of dZ), T = sum_v alpha t_v and their positive-branch parts -- no dot product, no
 // cross-lane reduction per edge.
+// Numerics of that split (review, round 5): del and der are DIFFERENCES of two sums of the size of t, not sums of alpha (dalpha - t).
+// Where every dalpha of a row lies close to t (near-uniform attention, or attention on one edge) the true value is small
+// against t and fp32 keeps it to eps |t|, not to eps |del|: |error(del, der)| <= ~32 eps max|t| on top of the usual 1e-4
+// relative (tests/test_gpu_gat_mh.py::test_gat_mh_sweep_score_gradients_when_attention_is_flat_or_peaked checks exactly this bound
+// in both regimes).  dz, dW and the sums da_l / da_r keep the relative criterion; the blocked kernels (gatmh_sweep = 0) sum edge by edge.
 // Inside the sweep everything is in log2 units (a_l, er, m scaled by log2 e once): exp(s - m) = v_exp_f32(max(t1, t2)),
 // t1 = el' + c1, t2 = 0.2 el' + c2 with c1 = er' - m', c2 = 0.2 er' - m' per (row, head) in an LDS table.
 #include "gat_mh.hpp"

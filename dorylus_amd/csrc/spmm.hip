@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
         col[k] = act[k] ? c0 + GROUP * k : 0;
         acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (a.accumulate == 2) {   // second pass of an edge-split aggregation: go on from the first pass's sum (same order of additions as one pass)
+        const float4 *o4 = reinterpret_cast<const float4 *>(a.out);
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k)
+            if (act[k]) acc[k] = o4[(size_t)v * nchunk + col[k]];
+    }
 
     const float4 *xl4 = reinterpret_cast<const float4 *>(a.xl);
     const float4 *xg4 = reinterpret_cast<const float4 *>(a.xg);
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     }
 
     uint64_t e = row_ok ? a.ptr[v] : 0;
-    uint64_t end = row_ok ? a.ptr[v + 1] : 0;
+    uint64_t end = row_ok ? (a.ptr_end ? a.ptr_end[v] : a.ptr[v + 1]) : 0;
     if (a.row_clamp && end - e > a.row_clamp) end = e + a.row_clamp;   // the rest of a long row: spmm_longrow_kernel
     // GROUP == 64: the loop is wave-uniform (one row per wave).
     while (e < end) {
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     for (int k = 0; k < CHUNKS; ++k)
         if (act[k]) {
             const size_t o = (size_t)v * nchunk + col[k];
-            if (a.accumulate) {
+            if (a.accumulate == 1) {
                 float4 p = out4[o];
                 acc[k].x += p.x; acc[k].y += p.y; acc[k].z += p.z; acc[k].w += p.w;
             }

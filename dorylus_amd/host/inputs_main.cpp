@@ -12,7 +12,9 @@
 // an input of the hot path, so this tool offers deterministic METIS-free methods instead --
 // block (contiguous, balanced by vertex count; default), hash, bfs (breadth-first regions), ldg (restreamed linear
 // deterministic greedy: each vertex joins the partition that already holds most of its neighbours, damped by how full
-// that partition is; three passes; balanced within 5 % -- the one to use when the graph has community structure).
+// that partition is; --passes=N restreaming passes, ten by default; balanced within 5 % -- the one to use when the graph has
+// community structure: on the Amazon-size 50-community graph with shuffled ids it cuts 14.9 % of the edges where contiguous
+// blocks cut 87.5 % and the generator's own community order 17.4 %).
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -172,7 +174,7 @@ static int labelstobinary(int argc, char **argv) {
 static int partitioner(int argc, char **argv) {
     std::vector<std::string> pos;
     std::string method = "block";
-    int passes = 3;
+    int passes = 10;   // (three passes leave half of the edges of a 50-community graph cut: 0.49; ten: 0.149 -- profiles/r06_partition_quality_amazon_community.json)
     for (int i = 1; i < argc; ++i) {
         if (!strncmp("--method=", argv[i], 9)) method = argv[i] + 9;
         else if (!strncmp("--passes=", argv[i], 9)) passes = std::max(1, atoi(argv[i] + 9));   // ldg: restreaming passes

@@ -192,7 +192,9 @@ def gen_numpy_gnn_large(name, dims, V=1500, E=18000, seed=23, rows=96, hub=False
     sample = np.sort(np.random.default_rng(seed + 2).choice(V, rows, replace=False))
     if hub:
         sample = np.unique(np.concatenate([sample, [3, 5]]))          # the hub rows are always among the compared rows
-    store = {"V": V, "src": src, "dst": dst, "X_q64": Xq, "labels": labels, "sample": sample, "dims": np.asarray(dims)}
+    et = np.uint16 if V <= 65536 and V > 8192 else np.uint32       # (the 20 000-vertex fixture: two bytes per endpoint)
+    store = {"V": V, "src": src.astype(et), "dst": dst.astype(et), "X_q64": Xq, "labels": labels.astype(np.uint8 if dims[-1] < 256 and V > 8192 else np.uint32),
+             "sample": sample, "dims": np.asarray(dims)}
     for l in range(L):
         store[f"W{l}"] = Ws[l]
     for k, v in out.items():
@@ -225,3 +227,6 @@ if __name__ == "__main__":
     gen_numpy_gnn_large("numpy_gnn_amazon_dims", [300, 64, 64, 25], seed=29)  # config 4: 3 layers
     # round 5: 4 096 vertices (the dense A_hat of the Python model still fits) with two hub rows of ~3 500 neighbours
     gen_numpy_gnn_large("numpy_gnn_hub4k", [602, 128, 41], V=4096, E=40000, seed=31, rows=128, hub=True)
+    # round 6: 20 000 vertices, ~590 000 edges, hub rows of ~13 000 neighbours (beyond K1's long-row clamp of 8 192) -- the largest
+    # graph the Python model's dense A_hat (3.2 GB) handles in minutes; widths 128-64-16
+    gen_numpy_gnn_large("numpy_gnn_20k", [128, 64, 16], V=20000, E=300000, seed=37, rows=192, hub=True)

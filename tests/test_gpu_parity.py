@@ -591,13 +591,13 @@ def test_gcn_numpy_gnn_fixture(da, golden_dir):
     from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
     V = int(z["V"])
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     dims = [z["X"].shape[1], z["W0"].shape[1], z["W1"].shape[1]]
     ctx = make_ctx(da, g, dims, V)
     ctx.upload(0, "x", z["X"])
     ctx.weight_set(0, "w", z["W0"])
     ctx.weight_set(1, "w", z["W1"])
-    ctx.labels_upload(z["labels"])
+    ctx.labels_upload(z["labels"].astype(np.uint32))
     ctx.aggregate(0, da.FORWARD)
     ctx.apply_vertex(0, da.FORWARD)
     ctx.aggregate(1, da.FORWARD)
@@ -610,7 +610,7 @@ def test_gcn_numpy_gnn_fixture(da, golden_dir):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k", "numpy_gnn_20k"])
 def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
     """The reference's Python GCN at the widths of BASELINE configs 2 and 4 (602-128-41 / 300-64-64-25, 1 500 vertices):
     the forward half of the epoch through the C-ABI on the fixture's sampled rows."""
@@ -620,7 +620,7 @@ def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
     V = int(z["V"])
     dims = [int(x) for x in z["dims"]]
     L = len(dims) - 1
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     rows = z["sample"]
     for variant, nb in ((2, 8), (0, 0)):          # the sweep kernel (forced on this L2-sized graph) and the row gather
         ctx = make_ctx(da, g, dims, V)
@@ -629,7 +629,7 @@ def test_gcn_numpy_gnn_fixture_baseline_widths(da, golden_dir, name):
         ctx.upload(0, "x", z["X_q64"].astype(np.float32) / np.float32(64))
         for l in range(L):
             ctx.weight_set(l, "w", z[f"W{l}"])
-        ctx.labels_upload(z["labels"])
+        ctx.labels_upload(z["labels"].astype(np.uint32))
         for l in range(L):
             ctx.aggregate(l, da.FORWARD)
             ctx.apply_vertex(l, da.FORWARD)
@@ -654,14 +654,14 @@ def test_gcn_numpy_gnn_fixture_backward_half(da, golden_dir):
     from helpers import assert_parity, make_ctx, rel_err
     z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
     V = int(z["V"])
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     dims = [z["X"].shape[1], z["W0"].shape[1], z["W1"].shape[1]]
     for variant, nb in ((2, 8), (1, 8), (0, 0)):
         ctx = make_ctx(da, g, dims, V, options={"spmm_variant": variant, "spmm_blk_nb": nb})
         ctx.upload(0, "x", z["X"])
         ctx.weight_set(0, "w", z["W0"])
         ctx.weight_set(1, "w", z["W1"])
-        ctx.labels_upload(z["labels"])
+        ctx.labels_upload(z["labels"].astype(np.uint32))
         for l in range(2):
             ctx.aggregate(l, da.FORWARD)
             ctx.apply_vertex(l, da.FORWARD)
@@ -684,7 +684,7 @@ def test_gcn_numpy_gnn_fixture_backward_half(da, golden_dir):
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k", "numpy_gnn_20k"])
 def test_gcn_numpy_gnn_fixture_backward_half_baseline_widths(da, golden_dir, name):
     """The same at the widths of BASELINE configs 2 and 4 (any depth): upload the fixture's complete grad_{L-1}, run the
     backward stages of every layer below through the C-ABI, compare aTg_l, g_l, grad_l (sampled rows) and the complete
@@ -695,14 +695,14 @@ def test_gcn_numpy_gnn_fixture_backward_half_baseline_widths(da, golden_dir, nam
     V = int(z["V"])
     dims = [int(x) for x in z["dims"]]
     L = len(dims) - 1
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     rows = z["sample"]
     for variant, nb in ((2, 8), (0, 0)):
         ctx = make_ctx(da, g, dims, V, options={"spmm_variant": variant, "spmm_blk_nb": nb})
         ctx.upload(0, "x", z["X_q64"].astype(np.float32) / np.float32(64))
         for l in range(L):
             ctx.weight_set(l, "w", z[f"W{l}"])
-        ctx.labels_upload(z["labels"])
+        ctx.labels_upload(z["labels"].astype(np.uint32))
         for l in range(L):
             ctx.aggregate(l, da.FORWARD)
             ctx.apply_vertex(l, da.FORWARD)

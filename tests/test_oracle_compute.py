@@ -23,7 +23,7 @@ def rel_err(a, b):
 def fx(golden_dir):
     z = np.load(os.path.join(golden_dir, "numpy_gnn_epoch.npz"))
     V = int(z["V"])
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     return z, g
 
 
@@ -97,14 +97,14 @@ def _oracle_epoch_any_depth(z, g):
     return out
 
 
-@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k"])
+@pytest.mark.parametrize("name", ["numpy_gnn_reddit_dims", "numpy_gnn_amazon_dims", "numpy_gnn_hub4k", "numpy_gnn_20k"])
 def test_gcn_epoch_matches_numpy_gnn_at_baseline_widths(golden_dir, name):
     """The same pin at the widths of BASELINE configs 2 and 4 (602-128-41; 300-64-64-25, three layers), 1 500 vertices:
     every intermediate tensor on the fixture's sampled rows and both/all three complete weight gradients against the
     reference's numpy GCN (fixture made by oracle/gen_golden.py:gen_numpy_gnn_large)."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     V = int(z["V"])
-    g = po.preprocess(z["src"], z["dst"], np.zeros(V, np.int64), 0, 1)
+    g = po.preprocess(z["src"].astype(np.uint32), z["dst"].astype(np.uint32), np.zeros(V, np.int64), 0, 1)
     out = _oracle_epoch_any_depth(z, g)
     rows = z["sample"]
     checked = 0

@@ -30,6 +30,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_amz_k -o k -- python "$R/be
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_k -name '*.db' | head -1)" > "$OUT/${TAG}_k1_amazon_rank_kernel_stats.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_amz_f -o p -- python "$R/bench.py" --workload amazon --emulate 0/8 --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_amz_f.log 2>&1
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_f -name '*.db' | head -1)" > "$OUT/${TAG}_k1_amazon_rank_pmc_fetch_size.txt" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_${TAG}_amz_w -o p -- python "$R/bench.py" --workload amazon --emulate 0/8 --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_amz_w.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_amz_w -name '*.db' | head -1)" > "$OUT/${TAG}_k1_amazon_rank_pmc_write_size.txt" 2>&1
 # the community-ordered graph (bench.py --graph community): epoch + HBM-side bytes of its K1s launches
 python "$R/bench.py" --graph community --no-cpu-baseline --no-alt > "$OUT/${TAG}_bench_community.json" 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_com_f -o p -- python "$R/bench.py" --graph community --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_com_f.log 2>&1
@@ -39,6 +41,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_gmh_k -o k -- python "$R/be
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_k -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_kernel_stats.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_${TAG}_gmh_f -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_f.log 2>&1
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_f -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_fetch_size.txt" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_${TAG}_gmh_w -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_w.log 2>&1
+python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_w -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_write_size.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_${TAG}_gmh_v -o p -- python "$R/bench.py" --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt > /tmp/prof_${TAG}_gmh_v.log 2>&1
 python "$R/tools/rocprof_summary.py" "$(find /tmp/prof_${TAG}_gmh_v -name '*.db' | head -1)" > "$OUT/${TAG}_gatmh_pmc_valu.txt" 2>&1
 # the reference's single-head GAT prototype (rows a-6 / a-8): kernel summary of its epoch

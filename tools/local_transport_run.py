@@ -57,7 +57,16 @@ def main():
     lop = np.zeros(a.V, np.int32)
     lop[int(a.V * 0.98):] = 1
     configs.append(("rank0_holds_98pct", 2, lop, [{"spmm_sweep_cus": 24}, {"spmm_sweep_cus": 4}]))
+    # the row gather (K1) beside an exchange: a graph with community structure in community-aligned blocks (what the ldg
+    # partitioner recovers, profiles/r06_partition_quality_*.json), 85 % of every row's edges local -- K1's local-first edge
+    # split sums them while the ghost rows travel
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_partitions as mp
+    csrc, cdst = mp.community_edges(a.V, a.E, 8, 0.85)
+    graphs = {"balanced": (src, dst), "rank0_holds_98pct": (src, dst), "k1_community_blocks": (csrc, cdst)}
+    configs.append(("k1_community_blocks", 4, (np.arange(a.V, dtype=np.int64) * 4 // a.V).astype(np.int32), {"spmm_variant": 0}))
     for name, P, parts, share in configs:
+        src, dst = graphs[name]
         bits = {}
         for overlap in (1, 0):
             pobjs = [da.Partition.build(src, dst, parts, r, P) for r in range(P)]

@@ -92,7 +92,8 @@ def measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, steps, war
            "send_rows_fwd": [int(len(x)) for x in g["fwdLists"]], "send_rows_bwd": [int(len(x)) for x in g["bwdLists"]]}
     ctx = da.Context(0)
     ctx.configure(da.GCN, dims, V, 0, 1)          # one rank alone: no communicator, ghost rows stay what they are
-    part.upload(ctx, None)
+    ctx.set_option("spmm_blk_force_split", 1)     # the two-launch form of every aggregation, as beside an exchange in flight: its first
+    part.upload(ctx, None)                        # launch (local sources: timing family spmm_local_first) is what the exchange hides under
     ctx.preallocate()
     ctx.fill_uniform(0, "x", 1, -1.0, 1.0, g["localToGlobal"])
     if Gs:

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import spmm_source_stamp  # noqa: E402
+from bench import GATMH_STAMP_FILES, source_stamp, spmm_source_stamp  # noqa: E402
 
 
 def counter_sum(path, counter, pattern):
@@ -47,16 +47,35 @@ def main():
         amz = os.path.join(ROOT, "profiles", "r04_k1_amazon_rank_pmc_fetch_size.txt")
     if os.path.exists(amz):
         fetch_a, names_a = counter_sum(amz, "FETCH_SIZE", r"spmm_rows_kernel")
+        amz_w = os.path.join(ROOT, "profiles", f"{tag}_k1_amazon_rank_pmc_write_size.txt")
+        write_a = counter_sum(amz_w, "WRITE_SIZE", r"spmm_rows_kernel")[0] if os.path.exists(amz_w) else 0.0
         pm["amazon_rank0of8"] = {
             "kernels": "spmm_rows_kernel<32,3> (F=300) + 4 x spmm_rows_kernel<16,1> (F=64): the five aggregations of one epoch",
             "fetch_size_kb_per_epoch": round(fetch_a, 1), "fetch_bytes_per_epoch": int(2 * fetch_a * 1024),
-            "source": ["profiles/" + os.path.basename(amz)],
+            "write_size_kb_per_epoch": round(write_a, 1), "bytes_per_epoch": int((2 * fetch_a + write_a) * 1024),
+            "source": ["profiles/" + os.path.basename(amz)] + (["profiles/" + os.path.basename(amz_w)] if write_a else []),
             "spmm_hip_blob": spmm_source_stamp(),
             "note": "rocprofv3 --pmc FETCH_SIZE pass of `bench.py --workload amazon --emulate 0/8 --steps 1 --warmup 0 --no-cpu-baseline "
-                    "--no-alt` (tools/collect_profiles.sh); FETCH_SIZE doubled (gfx950); the write side (one N x ld row tensor per launch, "
-                    "1.1 GB per epoch) was not collected",
+                    "--no-alt` (tools/collect_profiles.sh) and, since round 6, the WRITE_SIZE pass of the same command; FETCH_SIZE doubled (gfx950)",
         }
         print("amazon_rank0of8", pm["amazon_rank0of8"]["fetch_bytes_per_epoch"], names_a)
+    # config 3 (8-head GAT): the four sweep kernels of one epoch (+ their combine kernels), FETCH and WRITE passes
+    gf = os.path.join(ROOT, "profiles", f"{tag}_gatmh_pmc_fetch_size.txt")
+    gw = os.path.join(ROOT, "profiles", f"{tag}_gatmh_pmc_write_size.txt")
+    if os.path.exists(gf) and os.path.exists(gw):
+        pat = r"gatmh_forward_sweep_kernel|gatmh_src_sweep_kernel|gatmh_sweep_combine"
+        fetch_g, names_g = counter_sum(gf, "FETCH_SIZE", pat)
+        write_g, _ = counter_sum(gw, "WRITE_SIZE", pat)
+        pm["gatmh_sweeps"] = {
+            "kernels": "gatmh_forward_sweep_kernel + gatmh_src_sweep_kernel, both layers (four edge passes per epoch)",
+            "fetch_size_kb_per_epoch": round(fetch_g, 1), "write_size_kb_per_epoch": round(write_g, 1),
+            "bytes_per_epoch": int((2 * fetch_g + write_g) * 1024),
+            "source": [f"profiles/{tag}_gatmh_pmc_fetch_size.txt", f"profiles/{tag}_gatmh_pmc_write_size.txt"],
+            "source_stamp": source_stamp(GATMH_STAMP_FILES),
+            "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --gnn gatmh --steps 1 --warmup 0 --no-cpu-baseline --no-alt`; "
+                    "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported",
+        }
+        print("gatmh_sweeps", pm["gatmh_sweeps"]["bytes_per_epoch"], names_g)
     json.dump(pm, open(p, "w"), indent=2)
     print(pm["spmm_variant_2"]["bytes_per_launch"], names)
 
