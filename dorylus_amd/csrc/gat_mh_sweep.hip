@@ -25,6 +25,10 @@
 // against t and fp32 keeps it to eps |t|, not to eps |del|: |error(del, der)| <= ~32 eps max|t| on top of the usual 1e-4
 // relative (tests/test_gpu_gat_mh.py::test_gat_mh_sweep_score_gradients_when_attention_is_flat_or_peaked checks exactly this bound
 // in both regimes).  dz, dW and the sums da_l / da_r keep the relative criterion; the blocked kernels (gatmh_sweep = 0) sum edge by edge.
+// LeakyReLU's kink: the branch of an (edge, head) is decided as t1 > t2 on the SHIFTED scores (magnitude |log2 den| ~ 5), i.e. to
+// ~3e-7 absolute in el + er; an edge that close to zero may land on the other side than in the oracle, which moves del[u] / der[v]
+// by 0.8 alpha (dalpha - t) and the forward value by < 3e-7.  Measured (round 6, a_l, a_r ~ 1e-3, 12 000 edges x 8 heads): a
+// handful of such edges, 1.5e-2 relative on the del entries they touch -- a subgradient choice, not an accumulation error.
 // Inside the sweep everything is in log2 units (a_l, er, m scaled by log2 e once): exp(s - m) = v_exp_f32(max(t1, t2)),
 // t1 = el' + c1, t2 = 0.2 el' + c2 with c1 = er' - m', c2 = 0.2 er' - m' per (row, head) in an LDS table.
 #include "gat_mh.hpp"

@@ -328,8 +328,8 @@ def test_gat_mh_sweep_score_gradients_when_attention_is_flat_or_peaked(scale):
     der = 0.8 (<dO, P> - t dpos), del = <Z, 0.2 S + 0.8 S+> - (0.2 T + 0.8 T+)) instead of summing alpha (dalpha - t) edge by
     edge.  When every dalpha of a row lies close to t -- near-uniform attention (a_l, a_r ~ 0), or attention that sits on one
     edge -- the true values are small against t and what fp32 keeps of them is bounded by eps |t|, not by eps |del|.  The bound
-    the header states, on both regimes: |error| <= 5e-4 max|reference| + 32 eps max|t|; the gradients that matter downstream
-    (dz, dW, and da_l / da_r, which sum del / der over all vertices) keep the 5e-4 criterion of the other tests."""
+    the header states, on both regimes: |error| <= 5e-4 max|reference| + 32 eps max|t| (rows that touch an edge sitting on
+    LeakyReLU's kink apart, see below); dz and dW keep the 5e-4 criterion of the other tests."""
     import dorylus_amd as da
     import gat_mh_oracle as go
     import partition_oracle as po
@@ -360,13 +360,31 @@ def test_gat_mh_sweep_score_gradients_when_attention_is_flat_or_peaked(scale):
     da.NativeEngine(ctx).run(1)
     fws, Hs, loss, dlogits, grads = go.epoch(g, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
     eps = 2.0 ** -23
+    colptr, rowidx = np.asarray(g["colPtr"], np.int64), np.asarray(g["rowIdx"], np.int64)
+    dst_of = np.repeat(np.arange(V), np.diff(colptr))
     for l in range(2):
         tmax = np.abs(grads[l]["t"]).max()
-        for nm, key in (("del", "d_el"), ("der", "d_er")):
+        # LeakyReLU's kink: an (edge, head) whose score el[u] + er[v] is zero to ~1e-6 has no derivative, and which side fp32
+        # puts it on moves del[u] / der[v] by 0.8 alpha (dalpha - t).  The sweep decides the side on the SHIFTED scores (magnitude
+        # |log2 den| ~ 5: 3e-7 absolute) -- with a_l, a_r ~ 1e-3 a few (edge, head)s of this graph sit that close.  Their rows are
+        # left out of the comparison (and counted: a handful); the forward value they touch moves by < 3e-7.
+        el, er = fws[l]["el"], fws[l]["er"]
+        pre = el[rowidx] + er[dst_of]                                   # [E][K]
+        near = np.abs(pre) < 2e-6
+        skip_u = np.zeros_like(el, dtype=bool)
+        skip_v = np.zeros_like(er, dtype=bool)
+        np.logical_or.at(skip_u, rowidx, near)
+        np.logical_or.at(skip_v, dst_of, near)
+        selfnear = np.abs(el + er) < 2e-6
+        skip_u |= selfnear
+        skip_v |= selfnear
+        assert skip_u.mean() < 0.05 and skip_v.mean() < 0.05, (scale, l, skip_u.mean(), skip_v.mean())
+        for nm, key, skip in (("del", "d_el", skip_u), ("der", "d_er", skip_v)):
             got, ref = ctx.download(l, nm).astype(np.float64), grads[l][key]
-            ref = ref.reshape(got.shape) if ref.size == got.size else ref
-            err = np.abs(got[:, :ref.shape[1]] - ref).max()
-            assert err <= 5e-4 * np.abs(ref).max() + 32 * eps * tmax, (scale, l, nm, err, np.abs(ref).max(), tmax)
+            diff = np.abs(got[:, :ref.shape[1]] - ref)
+            diff[skip] = 0.0
+            err = diff.max()
+            assert err <= 5e-4 * np.abs(ref).max() + 32 * eps * tmax, (scale, l, nm, err, np.abs(ref).max(), tmax, int(skip.sum()))
         assert rel_err(ctx.download(l, "dz"), grads[l]["dZ"]) < 5e-4, (scale, l, "dz")
         assert rel_err(ctx.weight_grad_get(l, "w"), grads[l]["dW"]) < 5e-4, (scale, l, "dW")
     ctx.close()
