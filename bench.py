@@ -868,16 +868,17 @@ def scaling_projection_for(workload, graph, world):
     per-rank measurements on one GPU + 153 GB/s per xGMI link): printed beside the measurement so that the first real
     multi-GPU record carries prediction and measurement side by side."""
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_scaling_projection.json")))
+        src = next(f for f in ("r06_scaling_projection.json", "r05_scaling_projection.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        pj = json.load(open(os.path.join(ROOT, "profiles", src)))
         case = pj["cases"][f"{workload}:{graph}"]
         e = case["by_P"][str(world)]
-        return {"available": True, "source": "profiles/r05_scaling_projection.json (tools/scaling_projection.py; projection, not a measurement)",
+        return {"available": True, "source": f"profiles/{src} (tools/scaling_projection.py; projection, not a measurement)",
                 "projected_epoch_ms": e["projected_epoch_ms"], "compute_ms_max_rank": e["compute_ms_max"], "compute_ms_mean": e["compute_ms_mean"],
                 "exposed_halo_ms_max_rank": e["exposed_halo_ms_max"], "allreduce_ms": e["allreduce_ms"],
                 "halo_bytes_per_exchange_max_peer": e["halo_bytes_per_exchange_max_peer"], "nnz_in_max_over_mean": e["nnz_in_max_over_mean"],
                 "single_gpu_epoch_ms": case.get("single_gpu_epoch_ms"), "projected_speedup": e.get("projected_speedup"),
                 "model": e["model"]}
-    except (OSError, KeyError, ValueError) as ex:
+    except (OSError, KeyError, ValueError, StopIteration) as ex:
         return {"available": False, "why": f"no projection on record for {workload}:{graph} x{world} ({type(ex).__name__})"}
 
 

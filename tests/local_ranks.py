@@ -9,7 +9,8 @@ import numpy as np
 TIMING_FAMS = ("spmm", "gemm", "halo", "halo_deferred", "halo_waited", "halo_hidden", "spmm_beside_halo", "allreduce")
 
 
-def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, timing=False, warm_epochs=0, downloads=()):
+def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, timing=False, warm_epochs=0, downloads=(), pre=None,
+              wnames=None):
     """parts_objs: da.Partition per rank; setup(ctx, rank, view) uploads inputs / weights / labels.  Returns a dict:
     tensors[rank][(layer, name)] for `downloads`, weights[rank][layer][name], wgrads likewise, timing (summed over the ranks), gates."""
     P = len(parts_objs)
@@ -18,6 +19,8 @@ def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, ti
     for r, part in enumerate(parts_objs):
         ctx = da.Context(0)
         ctx.configure(gnn, dims, V, r, P)
+        if pre:
+            pre(ctx)                          # (e.g. dory_gatmh_heads: before the tensors are laid out)
         for k, v in ((opts[r] if isinstance(opts, (list, tuple)) else opts) or {}).items():     # one dict for all ranks, or one per rank
             ctx.set_option(k, v)
         part.upload(ctx, parts_vec)          # adjacency + both halo plans (host/partition.cpp)
@@ -58,7 +61,7 @@ def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, ti
     all_ranks(epochs)
     out = {"tensors": [], "weights": [], "wgrads": [], "epoch_ms": [np.asarray(m) for m in epoch_ms], "views": [p.view() for p in parts_objs]}
     L = len(dims) - 1
-    wnames = ("w", "a_i") if gnn == da.GAT else ("w",)
+    wnames = wnames or (("w", "a_i") if gnn == da.GAT else ("w",))
     for r, c in enumerate(ctxs):
         vw = out["views"][r]
         N, Gs, Gd = int(vw["localVtxCnt"]), int(vw["srcGhostCnt"]), int(vw["dstGhostCnt"])

@@ -246,3 +246,62 @@ def test_local_transport_refuses_bad_groups_and_times_out(da):
     ctxs[1].sync()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_local_transport_gat_mh_epoch_vs_oracle(da, P):
+    """the 8-head extension across P ranks over the same transport, whole epochs inside the Engine: z travels forward into fg_z,
+    and the backward sweep ships dO and the packed statistics between its two phases itself (exchange_rows, not deferred) --
+    against the single-partition float64 definition (oracle/gat_mh_oracle.py; parity unpinned: no reference implementation)"""
+    import gat_mh_oracle as go
+    import partition_oracle as po
+    from helpers import rel_err
+    from local_ranks import run_local
+    dims, heads, V, E = [40, 128, 41], [8, 1], 240, 2600
+    rng = np.random.default_rng(17)
+    s, d = rng.integers(0, V, E), rng.integers(0, V, E)
+    d[:200] = 7
+    s[200:400] = 13
+    parts = (rng.permutation(V) % P).astype(np.int32)
+    g_all = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    X = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    params = []
+    for l in range(2):
+        zw = dims[l + 1] * (heads[l] if l == 1 else 1)
+        params.append([(rng.standard_normal((dims[l], zw)) / np.sqrt(dims[l])).astype(np.float32),
+                       (rng.standard_normal(zw) * 0.3).astype(np.float32), (rng.standard_normal(zw) * 0.3).astype(np.float32)])
+
+    def setup(ctx, r, g):
+        ctx.upload(0, "h", X[g["localToGlobal"]])
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l, (W, al, ar) in enumerate(params):
+            ctx.weight_set(l, "w", W)
+            ctx.weight_set(l, "a_l", al)
+            ctx.weight_set(l, "a_r", ar)
+    pobjs = [da.Partition.build(s.astype(np.uint32), d.astype(np.uint32), parts, r, P) for r in range(P)]
+    dl = [(l, nm) for l in range(2) for nm in ("z", "o", "t", "del", "der", "dz")] + [(1, "logits")]
+    out = run_local(da, pobjs, parts, dims, da.GATMH, 1, setup, {"spmm_blk_nb": 8}, downloads=dl, pre=lambda c: c.gatmh_heads(heads),
+                    wnames=("w", "a_l", "a_r"))
+    fws, Hs, loss, dlogits, grads = go.epoch(g_all, X, labels, [[p.astype(np.float64) for p in ps] for ps in params], heads)
+
+    def gathered(layer, name):
+        res = None
+        for r, vw in enumerate(out["views"]):
+            t = out["tensors"][r][(layer, name)]
+            if res is None:
+                res = np.zeros((V, t.shape[1]), np.float32)
+            res[vw["localToGlobal"]] = t
+        return res
+    for l in range(2):
+        assert rel_err(gathered(l, "z"), fws[l]["Z"]) < RTOL, (l, "z")
+        assert rel_err(gathered(l, "o"), fws[l]["O"]) < RTOL, (l, "o")
+        assert rel_err(gathered(l, "t"), grads[l]["t"]) < 5e-4, (l, "t")
+        assert rel_err(gathered(l, "del"), grads[l]["d_el"]) < 5e-4, (l, "del")
+        assert rel_err(gathered(l, "der"), grads[l]["d_er"]) < 5e-4, (l, "der")
+        assert rel_err(gathered(l, "dz"), grads[l]["dZ"]) < 5e-4, (l, "dz")
+        for nm, key in (("w", "dW"), ("a_l", "da_l"), ("a_r", "da_r")):     # the summed gradients, identical on every rank
+            assert rel_err(out["wgrads"][0][l][nm].reshape(np.shape(grads[l][key])), grads[l][key]) < 5e-4, (l, nm)
+            for r in range(1, P):
+                assert np.array_equal(out["wgrads"][r][l][nm], out["wgrads"][0][l][nm]), (l, nm, r)
+    assert rel_err(gathered(1, "logits"), Hs[2]) < RTOL

@@ -55,6 +55,9 @@ def test_pmc_traffic_stamp_follows_code_not_comments(tmp_path, monkeypatch):
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
         d = json.load(f)
     assert d["spmm_variant_2"]["spmm_hip_blob"] == bench.spmm_source_stamp()
+    # config 3's sweep kernels (round 6: gatmh.roofline.traffic) are stamped with gat_mh_sweep.hip + sweep_core.hpp
+    assert d["gatmh_sweeps"]["source_stamp"] == bench.source_stamp(bench.GATMH_STAMP_FILES)
+    assert d["gatmh_sweeps"]["bytes_per_epoch"] > 0 and d["amazon_rank0of8"]["bytes_per_epoch"] > d["amazon_rank0of8"]["fetch_bytes_per_epoch"]
     csrc = tmp_path / "dorylus_amd" / "csrc"
     csrc.mkdir(parents=True)
     for f in ("spmm.hip", "sweep_core.hpp"):
