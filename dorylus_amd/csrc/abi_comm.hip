@@ -79,7 +79,10 @@ int local_exchange_finish(dory_ctx *c) {
     const uint64_t s = c->local_seq;
     LocalGroup &grp = *c->local;
     for (uint32_t q = 0; q < c->numNodes; ++q) {
-        if (q == c->nodeId) continue;
+        // only the peers that send me rows: a peer that sends me nothing does not wait for my receive buffer either, may be
+        // exchanges ahead, and its event ring (two deep) would by then hold a LATER exchange's record -- one that can depend
+        // on work queued behind this very wait
+        if (q == c->nodeId || !p.recv_counts[q]) continue;
         dory_ctx *Q = grp.ctx[q];
         if (!Q) return fail(c, DORY_ERR_COMM, "local transport: rank %u has been destroyed", q);
         int rc = local_wait_posted(c, Q->posted_sent, s, q, "exchange");
