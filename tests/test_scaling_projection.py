@@ -22,7 +22,7 @@ def test_projection_model_hidden_and_exposed_exchanges():
     assert p["halo_bytes_per_exchange_max_peer"] == 100000 * 128 * 4
     assert abs(p["nnz_in_max_over_mean"] - 1000 / 950) < 1e-3
     ex = p["per_rank"][0]["exchanges"]
-    assert len(ex) == 2 and ex[0]["dir"] == "fwd" and ex[1]["dir"] == "bwd" and abs(ex[0]["exchange_ms"] - (0.3346 + 0.0512 + 0.03)) < 2e-3
+    assert len(ex) == 2 and ex[0]["dir"] == "fwd" and ex[1]["dir"] == "bwd" and abs(ex[0]["exchange_ms"] - (0.3346 + 0.0410 + 0.03)) < 2e-3   # link + pack/unpack of 200 000 rows at the measured 5 TB/s + latency
     # nothing to hide under: every exchange is exposed in full
     slow = [_rank(0, 10.0, 0.0, [0, 100000], 100000, 100000, 1000), _rank(1, 9.0, 0.0, [100000, 0], 100000, 100000, 900)]
     q = sp.project(slow, dims, 2)

@@ -17,7 +17,7 @@ measurement of a real N > 1 run):
                       + pack and unpack at HBM_EFF + LAT
   exposed_ms        = max(0, exchange_ms - local_first_ms of the aggregation that consumes it)
   epoch_ms(P)       = max over ranks of (compute_ms + sum of exposed_ms over the epoch's exchanges) + allreduce_ms
-with LINK = 153 GB/s per direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU), HBM_EFF = 4 TB/s for the
+with LINK = 153 GB/s per direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU), HBM_EFF = 5 TB/s (measured, round 6: profiles/r06_pack_rate.json -- pack 5.8-6.1, unpack 4.7-4.8 TB/s of moved bytes on 3.1 M rows of 64 floats; rounds 5's 4 TB/s was a guess) for the
 row gathers / scatters of pack / unpack, LAT = 30 us per exchange (launches + group call), and the dW all-reduce as a
 ring: 2 (P - 1) / P x bytes / LINK + 2 (P - 1) x 10 us."""
 import argparse
@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 LINK_GBPS = 153.0
-HBM_EFF_GBPS = 4000.0
+HBM_EFF_GBPS = 5000.0
 LAT_MS = 0.030
 AR_HOP_MS = 0.010
 
@@ -124,7 +124,26 @@ def measure_rank(da, bench, workload, graph, src, dst, V, dims, r, P, steps, war
     return rec
 
 
+def reproject(path):
+    """recompute every projection of a stored file from its per-rank measurements with the current model constants (CPU only)"""
+    d = json.load(open(path))
+    for case in d["cases"].values():
+        for P, pr in case["by_P"].items():
+            new = project(pr["ranks"], case["dims"], int(P))
+            new["ranks"] = pr["ranks"]
+            if "single_gpu_epoch_ms" in case:
+                new["projected_speedup"] = round(case["single_gpu_epoch_ms"] / new["projected_epoch_ms"], 3)
+                new["projected_efficiency"] = round(new["projected_speedup"] / int(P), 3)
+            case["by_P"][P] = new
+    json.dump(d, open(path, "w"), indent=1)
+    return d
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--reproject":
+        d = reproject(sys.argv[2])
+        print(json.dumps({c: {P: v["projected_epoch_ms"] for P, v in r["by_P"].items()} for c, r in d["cases"].items()}))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_scaling_projection.json"))
     ap.add_argument("--cases", nargs="*", default=["reddit:uniform", "reddit:community", "amazon:uniform"])
