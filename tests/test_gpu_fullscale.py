@@ -500,3 +500,79 @@ def test_fullscale_friendster_rank_partition():
     N, Gs, nnz = int(g["localVtxCnt"]), int(g["srcGhostCnt"]), int(g["localInEdgeCnt"])
     assert abs(N - NB) <= 1 and Gs > 5.5e7 and abs(nnz - E / P) < 0.01 * E / P
     _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers=(1,), bwd_layer=1)
+
+
+def test_fullscale_reddit_two_ranks_over_the_local_transport_match_one_rank():
+    """BASELINE config 2 at full size, twice: one partition, and two contiguous-block ranks of one process over the in-process
+    device transport (dory_comm_init_local; driven stage by stage: every rank's scatter before any rank's next gather).  Forward:
+    ah@1 -- which needs the h@0 rows of the OTHER rank -- on 2 000 sampled rows against the one-partition run; backward: the same
+    grad@1 uploaded on both sides (the reference masks its loss per partition, so the runs' own gradients differ by design),
+    exchanged into bg@0, aggregated: aTg@0 on the sampled rows.  Ghost rows are the owners' rows bit for bit."""
+    import dorylus_amd as da
+    from bench import REDDIT_E, REDDIT_V, synth_edges
+    from helpers import rel_err
+    V, dims = REDDIT_V, [602, 128, 41]
+    src, dst = synth_edges("uniform", V, REDDIT_E)
+    labels = np.random.default_rng(2).integers(0, dims[-1], V).astype(np.uint32)
+    rng = np.random.default_rng(3)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
+    grad1 = rng.uniform(-1, 1, (V, dims[1])).astype(np.float32)
+
+    def make(part, r, P, parts_vec, opts):
+        g = part.view()
+        ctx = da.Context(0)
+        ctx.configure(da.GCN, dims, V, r, P)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        part.upload(ctx, parts_vec)
+        ctx.preallocate()
+        ctx.fill_uniform(0, "x", 1, -1.0, 1.0, g["localToGlobal"])            # keyed by global id: the same row whichever rank holds it
+        if int(g["srcGhostCnt"]):
+            ctx.fill_uniform(0, "fg", 1, -1.0, 1.0, g["srcGhost"])
+        ctx.labels_upload(labels[g["localToGlobal"]])
+        for l, W in enumerate(Ws):
+            ctx.weight_set(l, "w", W)
+        return ctx, g
+
+    part1 = da.Partition.build(src, dst, np.zeros(V, np.int32), 0, 1)
+    ctx, g1 = make(part1, 0, 1, None, {})
+    ctx.aggregate(0, da.FORWARD); ctx.apply_vertex(0, da.FORWARD); ctx.aggregate(1, da.FORWARD)
+    ctx.upload(1, "grad", grad1)
+    ctx.aggregate(1, da.BACKWARD)
+    one = {"ah1": ctx.download(1, "ah"), "aTg0": ctx.download(0, "aTg"), "h0": ctx.download(0, "h")}
+    ctx.close()
+    del part1
+    parts = (np.arange(V, dtype=np.int64) * 2 // V).astype(np.int32)
+    pobjs = [da.Partition.build(src, dst, parts, r, 2) for r in range(2)]
+    del src, dst
+    made = [make(pobjs[r], r, 2, parts, {"spmm_sweep_cus": 14}) for r in range(2)]
+    ctxs, gs = [m[0] for m in made], [m[1] for m in made]
+    da.Context.comm_init_local(ctxs)
+    for c in ctxs:
+        c.aggregate(0, da.FORWARD)
+        c.apply_vertex(0, da.FORWARD)
+    for c in ctxs:
+        c.halo_exchange(1, da.FORWARD)            # first halves: pack + copies into the peer, nothing waits on the host
+    for c in ctxs:
+        c.aggregate(1, da.FORWARD)                # local-source blocks beside the exchange, then its second half, then the ghost blocks
+    for c, g in zip(ctxs, gs):
+        c.upload(1, "grad", grad1[g["localToGlobal"]])
+    for c in ctxs:
+        c.halo_exchange(1, da.BACKWARD)
+    for c in ctxs:
+        c.aggregate(1, da.BACKWARD)
+    for c in ctxs:
+        c.sync()
+    rows = np.sort(np.random.default_rng(4).choice(V, 2000, replace=False))
+    ah1 = np.concatenate([c.download(1, "ah") for c in ctxs])                   # contiguous blocks: rank order = vertex order
+    aTg0 = np.concatenate([c.download(0, "aTg") for c in ctxs])
+    assert rel_err(ah1[rows], one["ah1"][rows]) < 1e-4
+    assert rel_err(aTg0[rows], one["aTg0"][rows]) < 1e-4
+    h0 = np.concatenate([c.download(0, "h") for c in ctxs])                     # (the one-partition h@0 sums in another order: last bits differ)
+    assert rel_err(h0[rows], one["h0"][rows]) < 1e-4
+    for c, g in zip(ctxs, gs):                    # what travelled: h@0 forward, grad@1 backward -- the owners' bits
+        assert np.array_equal(c.download(1, "fg"), h0[g["srcGhost"]])
+        assert np.array_equal(c.download(0, "bg"), grad1[g["dstGhost"]])
+    assert all(int(c.get_option("spmm_gate_timeouts")) == 0 for c in ctxs)
+    for c in ctxs:
+        c.close()
