@@ -235,6 +235,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["gatmh_blocked"] = 1;         // multi-head GAT: source-blocked (L2-resident) gathers where the blocked adjacency applies
     c->opt["gatmh_el_on_the_fly"] = 1;       // multi-head GAT, blocked forward with fused statistics, heads of <= 16 features: el[src] from the gathered row instead of a second gather
     c->opt["gatmh_sweep"] = 1;               // multi-head GAT: the edge passes on K1s's skeleton (gat_mh_sweep.hip) where the sweep layout and the shape apply (1: forward)
+    c->opt["gatmh_src_window_kb"] = 0;       // multi-head GAT: source window of the OUT-edge sweep layout in KB of 512-byte rows (0 = as the forward's, 4608)
     c->opt["gatmh_sweep_rows"] = 0;          // rows per lane group of the multi-head GAT contexts' sweep layouts (0 = by fill, at most 8)
     c->opt["gatmh_fused_stats"] = 1;         // multi-head GAT, blocked forward: online softmax per source block + merge in the reduce (0: separate statistics pass first)
     c->opt["gcn_cache_ah0"] = 0;         // GCN: keep ah@0 = A_hat x across epochs while x, fg@0 and the adjacency are unchanged (opt-in; the reference recomputes it)

@@ -77,8 +77,12 @@ int ensure_sweep(dory_ctx *c, bool csc, int group) {
     // = 3.34 / 3.22 / 3.16 / 3.21 / 3.38 ms per epoch; ranks of 4, 2 and the whole graph: 2432 KB stays best)
     // (multi-head GAT contexts: their sweeps carry 13-17 vector instructions per gather and two to four rows per group, and run
     // best on 4.5 MB windows -- 128-float forward 4.45 / 4.16 / 4.09 / 4.29 / 4.88 ms at 2432 / 3584 / 4608 / 6144 / 8192 KB)
+    // (round 6: the 8-head GAT's SOURCE side gathers a 128-byte statistics record beside every 512-byte row -- its window is a
+    // quarter larger than the forward's for the same rows, and at 4.5 MB of rows it ran fabric-bound: 29.6 GB fetched in 5.1 ms
+    // per 128-float launch; the out-edge layout therefore gets its own window, option gatmh_src_window_kb)
+    const uint64_t gat_kb = (c->gnn == DORY_GATMH && !csc && c->opt["gatmh_src_window_kb"]) ? (uint64_t)c->opt["gatmh_src_window_kb"] : 4608u;
     const uint64_t window_kb = c->opt["spmm_sweep_window_kb"] ? (uint64_t)c->opt["spmm_sweep_window_kb"]
-                                                              : (c->gnn == DORY_GATMH && R >= 4 ? 4608u : (R <= 4 ? 3584u : 2432u));
+                                                              : (c->gnn == DORY_GATMH && R >= 4 ? gat_kb : (R <= 4 ? 3584u : 2432u));
     const uint64_t window = window_kb << 10;
     const uint64_t nb_est = ((uint64_t)NG * group * 16u + window - 1) / window + 1;
     // the whole source slab in one L2 (Cora-sized graphs): K1 gathers from L2 anyway.  Thousands of windows (Amazon-,
