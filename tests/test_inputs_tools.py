@@ -87,11 +87,13 @@ def test_ldg_partitioner_recovers_communities(tmp_path):
     (tmp_path / "graph").write_text("\n".join(f"{a} {b}" for a, b in zip(s, d)) + "\n")
     run(tmp_path, "graphtobinary", "--snapfile=graph", "--undirected=0", "--header=1")
     cuts = {}
-    for method in ("hash", "ldg"):
-        run(tmp_path, "partitioner", "graph.bsnap", str(V), str(P), f"--method={method}")
+    for method in ("hash", "ldg", "ldg1"):
+        extra = ["--passes=1"] if method == "ldg1" else []                      # one streaming pass only; the default is ten
+        run(tmp_path, "partitioner", "graph.bsnap", str(V), str(P), f"--method={method[:3] if method != 'hash' else method}", *extra)
         parts = np.loadtxt(tmp_path / f"parts_{P}" / "graph.bsnap.parts", dtype=np.int64)
         counts = np.bincount(parts, minlength=P)
         assert counts.max() <= V / P * 1.05 + 2
         keep = s != d
         cuts[method] = int((parts[s[keep]] != parts[d[keep]]).sum())
     assert cuts["ldg"] < 0.35 * cuts["hash"], cuts
+    assert cuts["ldg"] <= cuts["ldg1"], cuts            # restreaming never hurts here (round 6: 3 -> 10 passes by default)
