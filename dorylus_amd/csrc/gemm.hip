@@ -223,6 +223,9 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
 #ifndef GEMM_BM_WIDE
 #define GEMM_BM_WIDE 128   // rows per tile of the 128-wide shape; 64 (finer tail, 6 workgroups per CU) measured: NN 344 -> 339 us, TN 302 -> 348, NT 50 -> 44
 #endif
+#ifndef GEMM_BM_NARROW
+#define GEMM_BM_NARROW 128   // rows per tile of the 64-wide shape (N <= 64); 256 = every wave a 64 x 64 register tile (round 6 experiment)
+#endif
 static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bm, int bn) {
     const uint32_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if (tiles == 0) return 1;
@@ -238,7 +241,7 @@ static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bm, int bn) 
 
 size_t gemm_scratch_bytes(uint32_t M, uint32_t N, uint32_t K) {
     // only split-K (few output tiles, long K) uses scratch: one M x ld(N) partial per split
-    const uint32_t S = pick_splits(M, N, K, N > 64 ? GEMM_BM_WIDE : 128, N > 64 ? 128 : 64);   // (the two shapes of launch_gemm)
+    const uint32_t S = pick_splits(M, N, K, N > 64 ? GEMM_BM_WIDE : GEMM_BM_NARROW, N > 64 ? 128 : 64);   // (the two shapes of launch_gemm)
     return S > 1 ? (size_t)S * M * pad_ld(N) * sizeof(float) : 0;
 }
 
@@ -292,7 +295,7 @@ hipError_t launch_gemm(const GemmArgs &g, float *scratch, size_t scratch_bytes, 
     if ((g.lda & 3u) || (g.ldb & 3u) || (reinterpret_cast<uintptr_t>(g.A) & 15u) || (reinterpret_cast<uintptr_t>(g.B) & 15u))
         return hipErrorInvalidValue;
     if (g.N > 64) return launch_bn<128, 2, 2, GEMM_BM_WIDE / 64, 2, 16>(g, scratch, scratch_bytes, s);
-    return launch_bn<64, 4, 1, 1, 2, 16>(g, scratch, scratch_bytes, s);
+    return launch_bn<64, 4, 1, GEMM_BM_NARROW / 128, 2, 16>(g, scratch, scratch_bytes, s);
 }
 
 }  // namespace dory
