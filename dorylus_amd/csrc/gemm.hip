@@ -224,7 +224,8 @@ __global__ void splitk_reduce_kernel(float *C, const float *partial, uint32_t M,
 #define GEMM_BM_WIDE 128   // rows per tile of the 128-wide shape; 64 (finer tail, 6 workgroups per CU) measured: NN 344 -> 339 us, TN 302 -> 348, NT 50 -> 44
 #endif
 #ifndef GEMM_BM_NARROW
-#define GEMM_BM_NARROW 128   // rows per tile of the 64-wide shape (N <= 64); 256 = every wave a 64 x 64 register tile (round 6 experiment)
+#define GEMM_BM_NARROW 128   // rows per tile of the 64-wide shape (N <= 64); 256 (every wave a 64 x 64 register tile, 140 VGPRs) measured round 6:
+                             // Amazon 300 -> 64: NN 602 -> 595-602 us, TN 544-551 -> 687-691; Reddit 128 -> 41: NN 61 -> 64, TN 85 -> 113 us
 #endif
 static uint32_t pick_splits(uint32_t M, uint32_t N, uint32_t K, int bm, int bn) {
     const uint32_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
