@@ -240,7 +240,13 @@ int dory_timing_reset(dory_ctx *ctx);
  * with equal id & 7 share an XCD, eight XCDs -- is checked once per context at dory_create with HW_REG_XCC_ID probes:
  * read-only "spmm_xcd_mapping_ok", "spmm_xcd_count"; when it does not hold, the first repeatable K1s launch is timed with
  * and without gates and the faster form kept ("spmm_xcd_policy": -1 nothing to decide, 0 gated, 8 ungated;
- * "spmm_xcd_gated_us" / "spmm_xcd_ungated_us"); "spmm_xcd_assume_mismatch" = 1 forces that path (tests). */
+ * "spmm_xcd_gated_us" / "spmm_xcd_ungated_us"); "spmm_xcd_assume_mismatch" = 1 forces that path (tests).
+ * Round 6: "spmm_edge_split" (default 1; before dory_graph_upload): K1 on GCN partitions with ghosts walks a local-first copy
+ * of every row's edges, so that an exchange in flight hides under the local-source part of EVERY row; "spmm_sweep_cus"
+ * (before dory_graph_upload): workgroups per sweep and XCD of the gated sweeps, for contexts that share a device
+ * (dory_comm_init_local); "local_timeout_ms"; "spmm_order" = 3 (before the upload): rows by median source id (experiment);
+ * "gatmh_src_window_kb": the 8-head GAT's out-edge sweep layout on its own source window.  The timing family
+ * "spmm_local_first" is the first launch of a two-launch aggregation when no exchange is in flight ("spmm_blk_force_split"). */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
 /* Diagnostic (no reference counterpart): hold `workgroups` whole CUs for `usec` microseconds with a sleeping kernel on
