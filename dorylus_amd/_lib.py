@@ -18,7 +18,7 @@ SYMBOLS = [
     "dory_configure", "dory_graph_upload", "dory_preallocate", "dory_tensor_info",
     "dory_tensor_upload", "dory_tensor_download", "dory_tensor_fill_uniform", "dory_labels_upload",
     "dory_weight_set", "dory_weight_get", "dory_weight_grad_get", "dory_weight_grad_set", "dory_weights_init_xavier",
-    "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat",
+    "dory_aggregate", "dory_apply_vertex", "dory_apply_edge", "dory_predict_gat", "dory_train_stat", "dory_train_stat_global",
     "dory_halo_plan", "dory_comm_unique_id", "dory_comm_init", "dory_halo_exchange", "dory_halo_pack",
     "dory_halo_unpack", "dory_halo_pack_tensor", "dory_halo_unpack_tensor", "dory_adam_config", "dory_weight_update", "dory_timing_enable",
     "dory_timing_get", "dory_timing_reset", "dory_set_option", "dory_get_option", "dory_ctx_describe",
@@ -72,6 +72,7 @@ def load():
         "dory_apply_edge": [vp, u32, i32],
         "dory_predict_gat": [vp, u32],
         "dory_train_stat": [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)],
+        "dory_train_stat_global": [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)],
         "dory_halo_plan": [vp, i32, vp, vp, vp, vp],
         "dory_comm_unique_id": [vp],
         "dory_comm_init": [vp, vp, i32, i32],
@@ -274,6 +275,12 @@ class Context:
     def train_stat(self):
         a, l, n = C.c_float(), C.c_float(), C.c_uint32()
         self._ck(self.lib.dory_train_stat(self.h, C.byref(a), C.byref(l), C.byref(n)))
+        return a.value, l.value, n.value
+
+    def train_stat_global(self):
+        """the same summed over all partitions (a collective: every rank calls it)"""
+        a, l, n = C.c_float(), C.c_float(), C.c_uint32()
+        self._ck(self.lib.dory_train_stat_global(self.h, C.byref(a), C.byref(l), C.byref(n)))
         return a.value, l.value, n.value
 
     # -- halo / comm ------------------------------------------------------------------------

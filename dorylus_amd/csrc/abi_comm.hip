@@ -149,7 +149,8 @@ static int local_exchange_send(dory_ctx *c, int dir, Tensor *src, Tensor *ghost,
 }
 
 // weight-gradient sum over the group: every rank adds the P gradients in rank order (identical bits on every rank)
-static int local_allreduce(dory_ctx *c, uint32_t layer, const std::string &name, Tensor &g, uint64_t n) {
+// (`stat` = true: the three validation scalars in every context's d_stat3 instead of a weight gradient)
+static int local_allreduce(dory_ctx *c, uint32_t layer, const std::string &name, float *gd, uint64_t n, bool stat = false) {
     LocalGroup &grp = *c->local;
     const uint32_t P = c->numNodes;
     if (n * sizeof(float) > c->ar_tmp_cap) return fail(c, DORY_ERR_COMM, "local transport: gradient staging buffer too small (preallocate before dory_comm_init_local)");
@@ -165,6 +166,7 @@ static int local_allreduce(dory_ctx *c, uint32_t layer, const std::string &name,
             if (rc) return rc;
             HIPCK(c, hipStreamWaitEvent(c->compute, Q->ev_gready[t & 1], 0));
         }
+        if (stat) { pp.p[q] = Q->d_stat3; continue; }
         if (layer >= Q->wgrads.size()) return fail(c, DORY_ERR_COMM, "local transport: rank %u has no layer %u", q, layer);
         auto it = Q->wgrads[layer].find(name);
         if (it == Q->wgrads[layer].end() || (uint64_t)it->second.rows * it->second.ld != n)
@@ -183,7 +185,7 @@ static int local_allreduce(dory_ctx *c, uint32_t layer, const std::string &name,
         if (rc) return rc;
         HIPCK(c, hipStreamWaitEvent(c->compute, Q->ev_gdone[t & 1], 0));
     }
-    HIPCK(c, hipMemcpyAsync(g.d, c->ar_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, c->compute));
+    HIPCK(c, hipMemcpyAsync(gd, c->ar_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, c->compute));
     return DORY_OK;
 }
 
@@ -496,6 +498,39 @@ int dory_halo_unpack_tensor(dory_ctx *c, uint32_t layer, const char *name, int d
 }
 
 // ---------------------------------------------------------------------------------------
+// The validation statistics of the last forward pass summed over all partitions: what WeightServer::updateLocalAccLoss /
+// updateGlobalAccLoss do with the AccLoss records the graph servers send (src/weight-server/weightserver.cpp:190-262:
+// vtcsCnt, acc and loss added up over the nodes, then "Epoch %u, acc: %.4f, loss: %.4f" on node 0).  Every rank calls it
+// (a collective); every rank gets the sums.
+int dory_train_stat_global(dory_ctx *c, float *acc_sum, float *loss_sum, uint32_t *val_rows) {
+    CHECK_CTX(c);
+    { int wrc = wait_halo(c); if (wrc) return wrc; }
+    if (!c->d_stat3) return fail(c, DORY_ERR_ARG, "train_stat_global: context not created properly");
+    float h[3] = {0.f, 0.f, 0.f};
+    HIPCK(c, hipMemcpyAsync(h, c->d_stat, 2 * sizeof(float), hipMemcpyDeviceToHost, c->compute));
+    HIPCK(c, hipStreamSynchronize(c->compute));
+    h[2] = (float)c->val_rows;      // (exact below 2^24 rows per sum: Friendster's 6.6 M validation rows fit)
+    if (c->numNodes > 1 && c->tx_ar) {
+        if (c->tx_ar(c->tx_user, h, 3)) return fail(c, DORY_ERR_COMM, "train_stat_global: host transport allreduce failed");
+    } else if (c->numNodes > 1) {
+        HIPCK(c, hipMemcpyAsync(c->d_stat3, h, sizeof(h), hipMemcpyHostToDevice, c->compute));
+        if (c->local) {
+            int rc = local_allreduce(c, 0, "", c->d_stat3, 3, true);
+            if (rc) return rc;
+        } else {
+            if (!c->nccl) return fail(c, DORY_ERR_COMM, "train_stat_global: dory_comm_init not called");
+            NCCLCK(c, ncclAllReduce(c->d_stat3, c->d_stat3, 3, ncclFloat, ncclSum, (ncclComm_t)c->nccl, c->compute));
+        }
+        HIPCK(c, hipMemcpyAsync(h, c->d_stat3, sizeof(h), hipMemcpyDeviceToHost, c->compute));
+        HIPCK(c, hipStreamSynchronize(c->compute));
+    }
+    if (acc_sum) *acc_sum = h[0];
+    if (loss_sum) *loss_sum = h[1];
+    if (val_rows) *val_rows = (uint32_t)(h[2] + 0.5f);
+    return DORY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 int dory_adam_config(dory_ctx *c, float learning_rate) {
     CHECK_CTX(c);
     c->adam.lr = learning_rate;
@@ -530,7 +565,7 @@ int dory_weight_update(dory_ctx *c, uint32_t layer) {
             HIPCK(c, hipStreamSynchronize(c->compute));
         } else if (c->numNodes > 1 && c->local) {
             Timed t(c, "allreduce", c->compute);
-            int rc = local_allreduce(c, layer, name, g, n);
+            int rc = local_allreduce(c, layer, name, g.d, n);
             if (rc) return rc;
         } else if (c->numNodes > 1) {
             if (!c->nccl) return fail(c, DORY_ERR_COMM, "weight_update: dory_comm_init not called");

@@ -183,7 +183,8 @@ int dory_create(int device, dory_ctx **out) {
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->d_stat, 2 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&c->sweep_stat, SWEEP_STAT_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&c->sweep_stat, SWEEP_STAT_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&c->d_stat3, 256) != hipSuccess) {
         delete c;
         return fail(nullptr, DORY_ERR_HIP, "stream/event creation failed");
     }
@@ -316,6 +317,7 @@ int dory_destroy(dory_ctx *c) {
     if (c->recv_buf) (void)hipFree(c->recv_buf);
     if (c->d_stat) (void)hipFree(c->d_stat);
     if (c->sweep_stat) (void)hipFree(c->sweep_stat);
+    if (c->d_stat3) (void)hipFree(c->d_stat3);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->own_compute && c->compute) (void)hipStreamDestroy(c->compute);

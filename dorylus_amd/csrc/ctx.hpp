@@ -185,6 +185,7 @@ struct dory_ctx {
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
     float *d_stat = nullptr;  // [acc_sum, loss_sum]
+    float *d_stat3 = nullptr; // dory_train_stat_global: [acc_sum, loss_sum, validation rows] of this partition, then of all
     uint32_t val_rows = 0;
 
     // halo

@@ -248,6 +248,11 @@ int main(int argc, char **argv) {
         if (!gat) {
             CK(dory_train_stat(ctx, &acc, &loss, &valRows));
             if (valRows) printLog("batch Acc: %f, Loss: %f", acc / valRows, loss / valRows);  // CPU_comm.cpp:116
+            // the weight servers' sum over the nodes (weightserver.cpp:190-262), logged by node 0 in their words
+            float gacc = 0, gloss = 0;
+            uint32_t gRows = 0;
+            CK(dory_train_stat_global(ctx, &gacc, &gloss, &gRows));
+            if (nodeId == 0 && gRows) printLog("Epoch %u, acc: %.4f, loss: %.4f", ep + 1, gacc / gRows, gloss / gRows);
         }
     }
     time_t end_time = time(nullptr);

@@ -158,6 +158,11 @@ int dory_predict_gat(dory_ctx *ctx, uint32_t layer);
 /* validation accuracy / loss sums of the last forward pass
  * (CPUComm::getTrainStat, CPU_comm.cpp:448-462; MessageService::sendAccloss) */
 int dory_train_stat(dory_ctx *ctx, float *acc_sum, float *loss_sum, uint32_t *val_rows);
+/* The same summed over all partitions -- what the weight servers do with the AccLoss records the graph servers send them
+ * (WeightServer::updateLocalAccLoss / updateGlobalAccLoss, src/weight-server/weightserver.cpp:190-262: vtcsCnt, acc, loss
+ * added up over the nodes, "Epoch %u, acc: %.4f, loss: %.4f" on node 0).  A collective: every rank calls it, every rank gets
+ * the sums (RCCL all-reduce of three scalars, or the local / host transport).  num_nodes == 1: the local values. */
+int dory_train_stat_global(dory_ctx *ctx, float *acc_sum, float *loss_sum, uint32_t *val_rows);
 
 /* ---- ghost-vertex halo exchange (replaces Engine::scatterGCN/GAT +
  * verticesPushOut + ghostReceiver*, gcn_ops.cpp:204-362, engine/utils.cpp:623-650)

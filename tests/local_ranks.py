@@ -35,9 +35,13 @@ def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, ti
     errors = [None] * P
     epoch_ms = [None] * P
 
+    stats = [None] * P
+
     def drive(r, n):
         try:
             epoch_ms[r] = engs[r].run(n)
+            if gnn == da.GCN:              # the weight servers' sum of the validation statistics over the nodes: a collective
+                stats[r] = (ctxs[r].train_stat(), ctxs[r].train_stat_global())
             ctxs[r].sync()
         except Exception as e:      # a failing rank must not leave the others waiting for the test's timeout silently
             errors[r] = e
@@ -77,6 +81,7 @@ def run_local(da, parts_objs, parts_vec, dims, gnn, epochs, setup, opts=None, ti
                 tm[f][0] += ms
                 tm[f][1] += n
         out["timing"] = {f: {"ms": round(v[0], 4), "launches": v[1]} for f, v in tm.items()}
+    out["stats"] = stats
     out["gates"] = [{"timeouts": int(c.get_option("spmm_gate_timeouts")), "ungated_launches": int(c.get_option("spmm_ungated_launches"))}
                     for c in ctxs]
     for e in engs:

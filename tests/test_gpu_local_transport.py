@@ -98,6 +98,13 @@ def _check_vs_oracle(out, gs, T, dW, Wo, L, what):
                 assert np.array_equal(out["tensors"][r][(l, "fg")], np.stack([g2row[int(gv)][0] for gv in g["srcGhost"]])), (what, r, l, "fg bits")
             if g["localVtxCnt"] and g["dstGhostCnt"]:
                 assert np.array_equal(out["tensors"][r][(l - 1, "bg")], np.stack([g2row[int(gv)][1] for gv in g["dstGhost"]])), (what, r, l, "bg bits")
+    # the validation statistics summed over the partitions (dory_train_stat_global = the weight servers' updateGlobalAccLoss):
+    # the sum of the ranks' own, the same on every rank, and the oracle's
+    loc = [s[0] for s in out["stats"]]
+    for r, (mine, glob) in enumerate(out["stats"]):
+        assert glob[2] == sum(x[2] for x in loc) and glob == out["stats"][0][1], (what, r, glob)
+        assert abs(glob[0] - sum(x[0] for x in loc)) < 1e-3 and abs(glob[1] - sum(x[1] for x in loc)) <= 1e-5 * max(1.0, abs(glob[1])), (what, r, glob, loc)
+    assert abs(out["stats"][0][1][1] - sum(T[r].get("loss", 0.0) for r in range(len(gs)))) <= 1e-4 * max(1.0, abs(out["stats"][0][1][1])), what
     for r in range(1, len(gs)):
         for l in range(L):
             assert np.array_equal(out["wgrads"][r][l]["w"], out["wgrads"][0][l]["w"]), (what, r, l, "dW bits")

@@ -103,6 +103,12 @@ def _worker(rank, world, port, case, q):
         eng = da.NativeEngine(ctx)
         eng.run(epochs)
         ctx.sync()
+        # the validation statistics summed over the ranks (the weight servers' updateGlobalAccLoss): one more all-reduce of 3 floats
+        loc = ctx.train_stat()
+        glob = ctx.train_stat_global()
+        tl = torch.tensor([loc[0], loc[1], float(loc[2])], dtype=torch.float64)
+        dist.all_reduce(tl)
+        stat_err = max(abs(glob[0] - tl[0].item()), abs(glob[1] - tl[1].item()) / max(1.0, abs(tl[1].item())), abs(glob[2] - tl[2].item()))
 
         # ---- oracle: the same epochs over the same partitions, Adam on the summed gradients ----
         Wo = [w.copy() for w in Ws]
@@ -142,7 +148,8 @@ def _worker(rank, world, port, case, q):
             want = np.stack([g2row[int(gv)] for gv in g["srcGhost"]])
             errs["fg1_bits"] = 0.0 if np.array_equal(ctx.download(1, "fg"), want) else 1.0
         expect_a2a = epochs * 2 * (L - 1)
-        ok_calls = calls["a2a"] == expect_a2a and calls["ar"] == epochs * L
+        errs["stat_global"] = stat_err
+        ok_calls = calls["a2a"] == expect_a2a and calls["ar"] == epochs * L + 1
         eng.close()
         ctx.close()
         dist.barrier()
