@@ -70,16 +70,14 @@ namespace dory {
 #define GATMH_SRC_BATCH 3
 #endif
 // The source side's second gather (the destination's (c1', c2', t) record; the HL lanes of a head want the same 12 bytes):
-//   0  every lane loads it (round 5)
-//   1  only the first lane of each quad (of each pair when a head spans two lanes) loads it, under the EXEC mask; the
-//      others get it by a DPP quad broadcast
-//   2  as 1 without an EXEC change: the other lanes' offsets are out of range (the buffer resource answers zeros)
-//   3  ONE instruction per batch of entries instead of one per entry: the addresser's cost is per instruction
-//      (tools/probes/aux_gather_probe.hip: forms 1 and 2 buy nothing), so lane j of a quad fetches the record of the batch's
-//      entry j and the quad's lanes get entry u's record by a DPP quad broadcast (heads of two lanes: two entries per instruction)
-// Measured (round 6, Reddit-large, 8 heads; profiles/r06_gatmh_aux_forms.txt): 32-lane launch 4.96 (0) / 5.25 (1) / 5.09 (2) /
-// 4.87 ms (3); 16-lane launch with batches of four 2.91 -> 2.77 ms (3).  The probe's 30 % (one gather instruction in four gone)
-// does not arrive in the sweep: its steps are bound by the chain LDS -> gathers -> sums of 16 waves, not by the addresser alone.
+//   0  every lane loads it, once per entry (round 5)
+//   3  ONE instruction per BATCH of entries: the addresser's cost is per instruction (tools/probes/aux_gather_probe.hip), so
+//      lane j of a quad fetches the record of the batch's entry j and the quad's lanes get entry u's record by a DPP quad
+//      broadcast (heads of two lanes: two entries per instruction)
+// (1 / 2 -- only the quad leaders load, under the EXEC mask or with the other lanes out of range -- were measured and removed:
+// 5.25 / 5.09 against 4.96 ms.)  Measured (round 6, Reddit-large, 8 heads; profiles/r06_gatmh_aux_forms.txt): 32-lane launch
+// 4.96 (0) / 4.87 ms (3); 16-lane launch with batches of four 2.91 -> 2.77 ms (3).  The probe's 30 % (one gather instruction in
+// four gone) does not arrive in the sweep: its steps are bound by the chain LDS -> gathers -> sums of 16 waves, not by the addresser.
 #ifndef GATMH_SRC_AUX_MODE
 #define GATMH_SRC_AUX_MODE 3
 #endif
@@ -407,7 +405,6 @@ struct GatSrcSweepOp {
     uint32_t K, D, ldk, N, G;
     // per thread
     uint32_t k, hl, aux_b, qpos;
-    bool aux_leader;
     __amdgpu_buffer_rsrc_t rs2;
     const float2 *etab;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -437,7 +434,6 @@ struct GatSrcSweepOp {
         const uint32_t rowb = K * 16u;
         rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(ghost_launch ? stxg : stx), 0, (ghost_launch ? G : N) * rowb, 0x00020000);
         aux_b = k * 16u - (ghost_launch ? N : 0u) * rowb;
-        aux_leader = ((uint32_t)li & (HL >= 4 ? 3u : 1u)) == 0u;
         qpos = (uint32_t)li & (HL >= 4 ? 3u : 1u);
     }
     __device__ __forceinline__ RowC row_const(uint32_t lrow) const {
@@ -446,14 +442,7 @@ struct GatSrcSweepOp {
     }
     __device__ __forceinline__ Aux aux(uint32_t sidx, uint32_t, bool on) const {
         typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-#if GATMH_SRC_AUX_MODE == 1
-        u3 v = {0u, 0u, 0u};
-        if (aux_leader) v = __builtin_amdgcn_raw_buffer_load_b96(rs2, on ? __umul24(sidx, K * 16u) + aux_b : 0xFFFFFFFFu, 0, 0);
-#elif GATMH_SRC_AUX_MODE == 2
-        const u3 v = __builtin_amdgcn_raw_buffer_load_b96(rs2, (on && aux_leader) ? __umul24(sidx, K * 16u) + aux_b : 0xFFFFFFFFu, 0, 0);
-#else
         const u3 v = __builtin_amdgcn_raw_buffer_load_b96(rs2, on ? __umul24(sidx, K * 16u) + aux_b : 0xFFFFFFFFu, 0, 0);
-#endif
         return make_float3(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z));
     }
     // AUX_BATCH: the records of the batch's entries [0, n) -- lane (quad position j) fetches entry i * EPL + j with load i
@@ -481,14 +470,7 @@ struct GatSrcSweepOp {
         aux_spread<0, NB, NL>(rec, ax);
     }
     template <bool FULL>
-    __device__ __forceinline__ void entry(Row &r, const RowC &c, const float4 &x, const Aux &sv0, bool on) const {
-#if GATMH_SRC_AUX_MODE == 1 || GATMH_SRC_AUX_MODE == 2
-        // the record sits in the first lane of the quad (HL >= 4) or of the pair (HL == 2): quad_perm [0,0,0,0] / [0,0,2,2]
-        constexpr int QP = HL >= 4 ? 0x00 : 0xA0;
-        const Aux sv = make_float3(sw_dpp<QP>(sv0.x), sw_dpp<QP>(sv0.y), sw_dpp<QP>(sv0.z));
-#else
-        const Aux &sv = sv0;
-#endif
+    __device__ __forceinline__ void entry(Row &r, const RowC &c, const float4 &x, const Aux &sv, bool on) const {
         const f2 t = c.e + (f2){sv.x, sv.y};                     // (el' + c1', 0.2 el' + c2')
         float al = __builtin_amdgcn_exp2f(fmaxf(t.x, t.y));
         if constexpr (!FULL) al = on ? al : 0.f;                 // (an absent slot read zeros: exp2(el') is not zero)
