@@ -591,6 +591,7 @@ def main():
             "parity_unpinned": PARITY_UNPINNED,
             "kernel_ms_per_epoch": {k: round(v[0] / args.steps, 4) for k, v in fam.items() if v[1]},
             "halo_selfcheck": halo_ok, "halo_overlap": bool(world > 1), "multi_gpu": multi,
+            "multi_gpu_on_record": multi_gpu_on_record() if world == 1 else None,
             "setup_s": round(t_setup, 1),
         }
     eng.close()
@@ -880,6 +881,30 @@ def scaling_projection_for(workload, graph, world):
                 "model": e["model"]}
     except (OSError, KeyError, ValueError, StopIteration) as ex:
         return {"available": False, "why": f"no projection on record for {workload}:{graph} x{world} ({type(ex).__name__})"}
+
+
+def multi_gpu_on_record():
+    """What this repo has on record about N > 1 when the line itself is a 1-GPU run (no multi-GPU node has been available):
+    the projected epochs (tools/scaling_projection.py) and the overlapped halo schedule measured with real concurrency on ONE
+    GPU (P ranks of one process over dory_comm_init_local, tools/local_transport_run.py).  Pointers into profiles/, not
+    measurements of this run."""
+    rec = {"note": "from profiles/ (committed evidence), not measured by this run; no RCCL call has run with more than one rank"}
+    try:
+        src = next(f for f in ("r06_scaling_projection.json", "r05_scaling_projection.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        pj = json.load(open(os.path.join(ROOT, "profiles", src)))["cases"]
+        rec["projected_epoch_ms"] = {c: {P: v["projected_epoch_ms"] for P, v in r["by_P"].items()} for c, r in pj.items()}
+        rec["projection_source"] = "profiles/" + src
+    except (OSError, KeyError, ValueError, StopIteration):
+        pass
+    try:
+        lt = json.load(open(os.path.join(ROOT, "profiles", "r06_local_transport.json")))
+        rec["overlap_on_one_gpu"] = [{k: r[k] for k in ("config", "P", "halo_overlap", "epoch_ms_median_max_rank", "halo_overlap_fraction",
+                                                         "identical_bits_overlap_on_off")} |
+                                     {"gate_timeouts": sum(g["timeouts"] for g in r["spmm_gates"])} for r in lt["runs"]]
+        rec["overlap_source"] = "profiles/r06_local_transport.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return rec
 
 
 def set_gloo_transport(ctx, dist, torch, rank, world):

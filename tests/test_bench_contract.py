@@ -58,6 +58,15 @@ def test_parity_unpinned_is_declared_without_a_gpu():
     assert '"parity_unpinned": PARITY_UNPINNED' in open(os.path.join(ROOT, "bench.py")).read()
 
 
+def test_multi_gpu_on_record_points_at_committed_evidence():
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = bench.multi_gpu_on_record()
+    assert "not measured by this run" in rec["note"]
+    assert rec["projected_epoch_ms"]["reddit:uniform"]["8"] > 0 and os.path.exists(os.path.join(ROOT, rec["projection_source"]))
+    assert any(r["halo_overlap_fraction"] for r in rec["overlap_on_one_gpu"]) and all(r["identical_bits_overlap_on_off"] for r in rec["overlap_on_one_gpu"])
+
+
 def test_stdout_is_shielded_while_communicators_are_created():
     """RCCL writes a line to file descriptor 1 when a communicator is created; bench.py points fd 1 at stderr for that time"""
     code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
