@@ -407,6 +407,12 @@ def _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers, bwd_layer):
         ah = ctx.download(l, "ah")
         ref, _ = _oracle_rows_partition(g, "colPtr", "rowIdx", "cscVal", rows, 20 + l, 20 + l, "srcGhost", F)
         assert_parity(ah[rows], ref, l)
+        # the two-launch form K1 takes beside an exchange in flight (round 6: every row's local-source edges first, the
+        # ghost-source edges in a second launch that goes on from those sums): the same bits as the single launch, everywhere
+        ctx.set_option("spmm_blk_force_split", 1)
+        ctx.aggregate(l, da.FORWARD)
+        ctx.set_option("spmm_blk_force_split", 0)
+        assert np.array_equal(ctx.download(l, "ah"), ah), ("two-launch form", l)
         w = np.bincount(g["rowIdx"], weights=g["cscVal"].astype(np.float64), minlength=N + Gs)
         w[:N] += g["norm"].astype(np.float64)
         H = ctx.download(l - 1, "h")
@@ -428,6 +434,10 @@ def _rank_partition_suite(da, part, g, V, dims, agg_fwd_layers, bwd_layer):
     assert with_ghost_b > 0.9 * rows_b.size
     refb, _ = _oracle_rows_partition(g, "rowPtr", "colIdx", "csrVal", rows_b, 31, 31, "dstGhost", F)
     assert_parity(aTg[rows_b], refb, 'aTg[rows_b]')
+    ctx.set_option("spmm_blk_force_split", 1)
+    ctx.aggregate(l, da.BACKWARD)
+    ctx.set_option("spmm_blk_force_split", 0)
+    assert np.array_equal(ctx.download(l - 1, "aTg"), aTg), "two-launch form, backward"
     ctx.fill_uniform(l, "grad", 31, -2.0, 2.0, g["localToGlobal"])
     ctx.fill_uniform(l - 1, "bg", 31, -2.0, 2.0, g["dstGhost"])
     ctx.aggregate(l, da.BACKWARD)
