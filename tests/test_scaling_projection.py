@@ -70,3 +70,42 @@ def test_pmc_traffic_stamp_follows_code_not_comments(tmp_path, monkeypatch):
     with open(csrc / "spmm.hip", "a") as f:
         f.write("\nstatic int one_more_symbol;\n")
     assert bench.spmm_source_stamp() != base
+
+
+def test_partition_quality_counts_ghosts_and_peer_rows():
+    """tools/make_partitions.py: per-rank ghosts and per-peer rows of a partitioning, on a graph small enough to count by hand"""
+    import numpy as np
+    import make_partitions as mp
+    # 6 vertices, two ranks {0,1,2} / {3,4,5}; symmetric records
+    e = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 5), (1, 5)]
+    src = np.array([a for a, b in e] + [b for a, b in e], np.uint32)
+    dst = np.array([b for a, b in e] + [a for a, b in e], np.uint32)
+    parts = np.array([0, 0, 0, 1, 1, 1], np.int8)
+    q = mp.quality(src, dst, parts, 2)
+    r0, r1 = q["ranks"]
+    assert r0["vertices"] == 3 and r0["ghosts_src"] == 2 and r0["recv_rows_from"] == [0, 2]      # rank 0 gathers 3 and 5
+    assert r1["ghosts_src"] == 3 and r1["recv_rows_from"] == [3, 0]                               # rank 1 gathers 0, 1, 2
+    assert r0["send_rows_to"] == [0, 3] and r1["send_rows_to"] == [2, 0]
+    assert q["edge_cut_records"] == 6 and q["send_rows_max_peer"] == 3 and q["ghosts_src_max"] == 3
+    # the community generator keeps `inside` of its edges within a community of consecutive ids, and the shuffle is a relabelling
+    s, d = mp.community_edges(1000, 20000, 10, 0.9)
+    assert abs(((s // 100) == (d // 100)).mean() - 0.91) < 0.02
+    s2, d2, perm = mp.shuffled(1000, s, d)
+    assert np.array_equal(perm[s], s2) and sorted(perm.tolist()) == list(range(1000))
+
+
+def test_reproject_recomputes_from_stored_rank_measurements(tmp_path):
+    """--reproject: the committed projection is a pure function of its per-rank records and the model constants"""
+    import json
+    import shutil
+    import scaling_projection as sp
+    src = os.path.join(ROOT, "profiles", "r06_scaling_projection.json")
+    if not os.path.exists(src):
+        return
+    dst = tmp_path / "p.json"
+    shutil.copy(src, dst)
+    before = json.load(open(src))
+    after = sp.reproject(str(dst))
+    for c, r in before["cases"].items():
+        for P, v in r["by_P"].items():
+            assert abs(after["cases"][c]["by_P"][P]["projected_epoch_ms"] - v["projected_epoch_ms"]) < 1e-6, (c, P)
