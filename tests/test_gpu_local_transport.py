@@ -194,7 +194,7 @@ def test_local_transport_gat_prototype_epoch_vs_oracle(da, case):
     from helpers import assert_parity, oracle_gat_epoch_parts
     from local_ranks import run_local
     dims, L = [20, 16, 6], 2
-    runs = []
+    runs, runs50 = [], []
     for overlap in (1, 0):
         pobjs, parts = _golden(da, case)
         gs = [p.view() for p in pobjs]
@@ -215,6 +215,13 @@ def test_local_transport_gat_prototype_epoch_vs_oracle(da, case):
         dl = [(l, nm) for l in range(L) for nm in ("z", "ah", "grad", "aTg", "fg_z", "bg_d")]
         out = run_local(da, pobjs, parts, dims, da.GAT, 1, setup, {"spmm_blk_nb": 8, "halo_overlap": overlap}, downloads=dl)
         T, dWs, das = oracle_gat_epoch_parts(gs, parts, H0, labels, Ws, As)
+        # and 50 epochs back to back over the same transport: finite, moved, the same bits on every rank
+        long_run = run_local(da, _golden(da, case)[0], parts, dims, da.GAT, 50, setup, {"spmm_blk_nb": 8, "halo_overlap": overlap})
+        for l in range(L):
+            w0 = long_run["weights"][0][l]["w"]
+            assert np.isfinite(w0).all() and np.abs(w0 - Ws[l]).max() > 1e-4
+            assert all(np.array_equal(long_run["weights"][r][l]["w"], w0) for r in range(1, len(gs)))
+        runs50.append(long_run)
         for r, g in enumerate(gs):
             if not g["localVtxCnt"]:
                 continue
@@ -228,6 +235,7 @@ def test_local_transport_gat_prototype_epoch_vs_oracle(da, case):
             assert_parity(out["wgrads"][0][l]["w"], dWs[l], (case, "dW", l))
         runs.append(out)
     _same_bits(runs[0], runs[1], (case, "GAT overlap on / off"))
+    _same_bits(runs50[0], runs50[1], (case, "GAT 50 epochs, overlap on / off"))
 
 
 def test_local_transport_refuses_bad_groups_and_times_out(da):

@@ -65,6 +65,24 @@ def main():
     csrc, cdst = mp.community_edges(a.V, a.E, 8, 0.85)
     graphs = {"balanced": (src, dst), "rank0_holds_98pct": (src, dst), "k1_community_blocks": (csrc, cdst)}
     configs.append(("k1_community_blocks", 4, (np.arange(a.V, dtype=np.int64) * 4 // a.V).astype(np.int32), {"spmm_variant": 0}))
+    # parity of the same path at this size: one epoch of every balanced configuration against the oracle's epoch over the same
+    # partitions (every named tensor, max-norm ratio; criteria of tests/helpers.py)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from helpers import oracle_gcn_epoch, rel_err
+    out["oracle_check"] = []
+    for name, P, parts, share in configs[:2]:
+        pobjs = [da.Partition.build(src, dst, parts, r, P) for r in range(P)]
+        dl = [(l, nm) for l in range(L) for nm in ("ah",)] + [(l, nm) for l in range(L - 1) for nm in ("h", "aTg")] + [(l, "grad") for l in range(1, L)]
+        res = run_local(da, pobjs, parts, dims, da.GCN, 1, setup, dict(share, halo_overlap=1), downloads=dl)
+        T, dW = oracle_gcn_epoch(res["views"], parts, X, labels, Ws, a.V)
+        worst = 0.0
+        for r in range(P):
+            for (l, nm), t in res["tensors"][r].items():
+                worst = max(worst, rel_err(t, T[r][f"{nm}{l}"]))
+            for l in range(L):
+                worst = max(worst, rel_err(res["wgrads"][r][l]["w"], dW[l]))
+        out["oracle_check"].append({"config": name, "P": P, "max_rel_err_all_named_tensors_and_dW": float(worst), "within_1e-4": bool(worst < 1e-4)})
+        sys.stderr.write(json.dumps(out["oracle_check"][-1]) + "\n")
     for name, P, parts, share in configs:
         src, dst = graphs[name]
         bits = {}
