@@ -338,7 +338,10 @@ static int halo_tensors(dory_ctx *c, uint32_t layer, int dir, Tensor **src, Tens
         else { *src = find(c, layer, "grad"); *ghost = find(c, layer - 1, "bg"); }
     } else {
         if (layer == 0 || layer > c->L) return fail(c, DORY_ERR_ARG, "halo: layer %u out of range", layer);
-        if (dir == DORY_FORWARD) { *src = find(c, layer - 1, "z"); *ghost = find(c, layer - 1, "fg_z"); }  // gat_ops.cpp:277-287
+        if (dir == DORY_FORWARD) {   // gat_ops.cpp:277-287
+            *src = find(c, layer - 1, "z"); *ghost = find(c, layer - 1, "fg_z");
+            if (layer - 1 < c->gat_nsum_valid.size()) c->gat_nsum_valid[layer - 1] = 0;   // fg_z is about to change: the kept neighbour sum no longer holds
+        }
         else { *src = find(c, layer - 1, "grad"); *ghost = find(c, layer - 1, "bg_d"); }
     }
     if (!*src || !*ghost) return fail(c, DORY_ERR_ARG, "halo: tensors missing");

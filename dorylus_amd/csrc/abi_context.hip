@@ -228,6 +228,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["gat_reuse_nsum"] = 1;         // GAT prototype: the backward's dA-weighted aggregation from the forward's neighbour sum (abi_stages.hip)
     c->opt["spmm_edge_split"] = 1;        // K1 on GCN partitions with ghosts: every row's local-source edges first (set before dory_graph_upload)
     c->opt["spmm_sweep_cus"] = 0;         // K1s / GAT sweeps: workgroups per sweep and XCD (0 = all CUs of an XCD); see dory_set_option
     c->opt["local_timeout_ms"] = 30000;   // in-process device transport: how long a rank's host thread waits for a peer's host thread
@@ -574,8 +575,11 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "arow", N, 1);   // per-destination value of "A"  (all edges of a column are equal)
             mk(l, "drow", N, 1);   // per-destination value of "dA"
         }
+        for (uint32_t l = 0; l < L; ++l) mk(l, "nsum", N, d[l + 1]);   // unweighted neighbour sum of z (kept from the forward for the backward aggregation)
+        mk(0, "ones", N, 1);
         c->gat_arow_valid.assign(L, 0);
         c->gat_drow_valid.assign(L, 0);
+        c->gat_nsum_valid.assign(L, 0);
     }
     if (rc) return rc;
     for (uint32_t l = 0; l < L; ++l) {
@@ -692,6 +696,7 @@ int dory_preallocate(dory_ctx *c) {
             }
         }
     }
+    c->gat_ones_set = false;
     c->prealloc = true;
     return DORY_OK;
 }
@@ -747,6 +752,7 @@ int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const floa
     if (layer == 0) c->ah0_valid = false;                                    // x / fg@0 / ah@0 may have changed
     if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
     if (!strcmp(name, "dA") && layer < c->gat_drow_valid.size()) c->gat_drow_valid[layer] = 0;
+    if ((!strcmp(name, "z") || !strcmp(name, "fg_z")) && layer < c->gat_nsum_valid.size()) c->gat_nsum_valid[layer] = 0;
     return upload_dense(c, *t, host);
 }
 
@@ -765,6 +771,7 @@ int dory_tensor_fill_uniform(dory_ctx *c, uint32_t layer, const char *name, uint
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t) return fail(c, DORY_ERR_ARG, "tensor_fill: no tensor '%s' at layer %u", name ? name : "(null)", layer);
     if (layer == 0) c->ah0_valid = false;
+    if ((!strcmp(name, "z") || !strcmp(name, "fg_z")) && layer < c->gat_nsum_valid.size()) c->gat_nsum_valid[layer] = 0;
     uint32_t *ids = nullptr;
     if (global_row_ids && t->rows) {
         int rc = upload_array(c, &ids, global_row_ids, t->rows);

@@ -117,6 +117,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 uint32_t F, int accumulate, const float *row_scale = nullptr) {
     if (xl.ld != out.ld || (xg && xg->rows && xg->ld != xl.ld) || xl.cols != F)
         return fail(c, DORY_ERR_ARG, "spmm: tensor shapes disagree (F=%u ld %u/%u)", F, xl.ld, out.ld);
+    c->last_spmm_unit = false;
     SpmmArgs a{};
     a.N = c->N; a.F = F; a.ld = xl.ld;
     a.ptr = csc ? c->colPtr : c->rowPtr;
@@ -151,6 +152,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
                 c->partial_bytes = need;
             }
             if (S.nslots && (rc = ensure_scratch(c, (size_t)S.nslots * a.ld * sizeof(float)))) return rc;   // pieces of split rows
+            c->last_spmm_unit = row_scale != nullptr;
             uint32_t *done = reinterpret_cast<uint32_t *>(c->partial);
             uint32_t sflags = (uint32_t)c->opt["spmm_sweep_flags"];
             SweepCtl ctl;
@@ -212,6 +214,7 @@ static int spmm(dory_ctx *c, bool csc, const float *val, int self_mode, Tensor &
         BlockedAdj &B = csc ? c->blkIn : c->blkOut;
         const size_t need = blocked_partial_bytes(a, B);
         if (!(csc ? c->blkIn_na : c->blkOut_na) && B.nb > 0 && need <= ((size_t)48 << 30)) {
+            c->last_spmm_unit = row_scale != nullptr;
             if (need > c->partial_bytes) {
                 if (c->capturing) return fail(c, DORY_ERR_ARG, "epoch graph: partial buffer would have to grow while recording");
                 HIPCK(c, hipStreamSynchronize(c->compute));
@@ -586,10 +589,32 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
     // dory_apply_edge leaves, next to the per-edge tensors "A" / "dA", the one value all
     // edges of a destination share; while that is current the SpMM gathers unweighted
     // (K1b) and scales per row.  A caller that overwrote "A"/"dA" gets the general K1 path.
+    // Round 6: with scores that depend on the destination only, BOTH in-edge aggregations of a layer -- the forward's
+    // ah = z + arow (.) S and the backward's aTg += drow (.) S -- are row-scaled copies of ONE unweighted neighbour sum
+    // S[v] = sum over in-edges of z[src] (ghosts included).  The forward computes S (tensor "nsum", same K1s launch(es), unit
+    // weights), the backward reuses it: two aggregations per layer and epoch instead of three ("gat_reuse_nsum"; a caller who
+    // replaced z / fg_z / "A" / "dA" in between gets the general path).
+    Tensor *nsum = find(c, fl, "nsum"), *ones = find(c, 0, "ones");
+    const bool reuse = c->opt["gat_reuse_nsum"] && nsum && ones && fl < c->gat_nsum_valid.size() && z->ld == nsum->ld;
     if (dir == DORY_FORWARD) {
         NEED(ah, fl, "ah");
         Tensor *arow = find(c, fl, "arow");
         const bool fast = arow && fl < c->gat_arow_valid.size() && c->gat_arow_valid[fl];
+        if (fl < c->gat_nsum_valid.size()) c->gat_nsum_valid[fl] = 0;
+        if (fast && reuse && c->N) {
+            if (!c->gat_ones_set) {
+                HIPCK(c, hipMemsetD32Async((hipDeviceptr_t)ones->d, 0x3f800000, c->N, c->compute));
+                c->gat_ones_set = true;
+            }
+            int rc = spmm(c, true, c->cscVal, 0, *z, fgz, *nsum, c->dims[layer], 0, ones->d);
+            if (rc) return rc;
+            if (c->last_spmm_unit) {      // (K1 -- graphs without a blocked layout -- gathers with the per-edge values: not a unit sum)
+                Timed t(c, "spmm", c->compute);
+                HIPCK(c, launch_row_axpy(ah->d, nsum->d, arow->d, z->d, c->N, z->ld, c->compute));
+                c->gat_nsum_valid[fl] = 1;
+                return DORY_OK;
+            }
+        }
         return spmm(c, true, c->cscVal, 2, *z, fgz, *ah, c->dims[layer], 0, fast ? arow->d : nullptr);
     }
     NEED(grad, fl, "grad");
@@ -601,6 +626,11 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
     if (rc) return rc;
     Tensor *drow = find(c, fl, "drow");
     const bool fast = drow && fl < c->gat_drow_valid.size() && c->gat_drow_valid[fl];
+    if (fast && reuse && c->gat_nsum_valid[fl]) {
+        Timed t(c, "spmm", c->compute);
+        HIPCK(c, launch_row_axpy(aTg->d, nsum->d, drow->d, nullptr, c->N, aTg->ld, c->compute));
+        return DORY_OK;
+    }
     return spmm(c, true, dA->d, 0, *z, fgz, *aTg, c->dims[layer], 1, fast ? drow->d : nullptr);
 }
 
@@ -687,6 +717,7 @@ int dory_apply_vertex(dory_ctx *c, uint32_t layer, int dir) {
     if (!feats) return fail(c, DORY_ERR_ARG, "apply_vertex GAT: input missing");
     if (dir == DORY_FORWARD) {  // vtxNNForwardGAT (CPU_comm.cpp:161-169)
         NEED(z, layer, "z");
+        if (layer < c->gat_nsum_valid.size()) c->gat_nsum_valid[layer] = 0;   // a new z: the kept neighbour sum of the old one no longer holds
         return gemm(c, 0, 0, N, Fout, Fin, *feats, W, *z);
     }
     // vtxNNBackwardGAT (CPU_comm.cpp:171-188)

@@ -167,6 +167,9 @@ struct dory_ctx {
                                                 // it), workgroups of the launch in flight that have left
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
+    std::vector<char> gat_nsum_valid;    // GAT prototype: "nsum"@l holds the unweighted neighbour sum of the current z / fg_z (forward -> backward)
+    bool gat_ones_set = false;           // "ones"@0 filled
+    bool last_spmm_unit = false;         // the last spmm() gathered with unit weights and a per-row factor (K1s / K1b), not with per-edge values (K1)
     std::vector<char> gatmh_fwd_swept;   // multi-head GAT: the forward of this layer ran on the sweep skeleton ("op", "dpos" are current)
     float *partial = nullptr;
     size_t partial_bytes = 0;
@@ -371,6 +374,8 @@ hipError_t launch_onehot(float *d, uint64_t rows, uint32_t cols, uint32_t ld, co
                          hipStream_t s);
 hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t lds, uint64_t rows,
                            uint32_t cols, hipStream_t s);
+hipError_t launch_row_axpy(float *out, const float *S, const float *rs, const float *x /* nullptr: out += rs * S */, uint64_t rows, uint32_t ld,
+                           hipStream_t s);
 
 // K5 GAT edge kernels
 hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,

@@ -315,6 +315,26 @@ __global__ void pad_copy_kernel(float *dst, uint32_t ldd, const float *src, uint
     }
 }
 
+// out[v,:] = base[v,:] + rs[v] * S[v,:]   (base = out itself when accumulating, x otherwise): what is left of a GAT-prototype
+// aggregation once the unweighted neighbour sum S is known (abi_stages.hip: the reference's edge scores depend on the destination only)
+__global__ __launch_bounds__(256) void row_axpy_kernel(float *out, const float *S, const float *rs, const float *x, uint32_t ld4, uint64_t n4) {
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    const float4 *s4 = reinterpret_cast<const float4 *>(S), *x4 = reinterpret_cast<const float4 *>(x ? x : out);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float r = rs[i / ld4];
+        const float4 b = x4[i], sv = s4[i];
+        o4[i] = make_float4(fmaf(r, sv.x, b.x), fmaf(r, sv.y, b.y), fmaf(r, sv.z, b.z), fmaf(r, sv.w, b.w));
+    }
+}
+hipError_t launch_row_axpy(float *out, const float *S, const float *rs, const float *x /* nullptr: out += */, uint64_t rows, uint32_t ld,
+                           hipStream_t s) {
+    if (rows == 0 || ld == 0) return hipSuccess;
+    if (ld & 3) return hipErrorInvalidValue;
+    const uint64_t n4 = rows * (ld >> 2);
+    hipLaunchKernelGGL(row_axpy_kernel, dim3((uint32_t)std::min<uint64_t>(8192, (n4 + 255) / 256)), dim3(256), 0, s, out, S, rs, x, ld >> 2, n4);
+    return hipGetLastError();
+}
+
 hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t lds, uint64_t rows,
                            uint32_t cols, hipStream_t s) {
     if (rows == 0 || ldd == 0) return hipSuccess;

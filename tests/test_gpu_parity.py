@@ -914,9 +914,12 @@ def test_gat_stages_vs_oracle(da, case, dims, nb):
         ctx.close()
 
 
+@pytest.mark.parametrize("reuse", [1, 0])
 @pytest.mark.parametrize("nb", [0, 8])
-def test_gat_engine_epoch_vs_oracle(da, nb):
-    """Whole GAT epoch through the C++ Engine (stage order of pipeline.cpp for GAT) == oracle."""
+def test_gat_engine_epoch_vs_oracle(da, nb, reuse):
+    """Whole GAT epoch through the C++ Engine (stage order of pipeline.cpp for GAT) == oracle; with the forward's neighbour
+    sum reused by the backward's dA-weighted aggregation (gat_reuse_nsum, round 6: two aggregations per layer instead of
+    three where a blocked layout gathers with unit weights) and with every aggregation gathered afresh."""
     import orc
     import partition_oracle as po
     from helpers import make_ctx, oracle_gat_epoch, random_graph, rel_err
@@ -928,7 +931,7 @@ def test_gat_engine_epoch_vs_oracle(da, nb):
     labels = rng.integers(0, dims[-1], V).astype(np.uint32)
     Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
     As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(2)]
-    ctx = make_ctx(da, g, dims, V, gnn=da.GAT, options={"spmm_blk_nb": nb})
+    ctx = make_ctx(da, g, dims, V, gnn=da.GAT, options={"spmm_blk_nb": nb, "gat_reuse_nsum": reuse})
     ctx.upload(0, "h", H0)
     ctx.labels_upload(labels)
     for l in range(2):
@@ -936,7 +939,12 @@ def test_gat_engine_epoch_vs_oracle(da, nb):
         ctx.weight_set(l, "a_i", As[l])
     ctx.adam_config(0.01)
     eng = da.NativeEngine(ctx)
+    ctx.timing_enable(True)
     eng.run(1)
+    ms, launches = ctx.timing_get("spmm")
+    ctx.timing_enable(False)
+    if nb:      # the blocked layouts' unit-weight gathers: the reuse replaces one sweep per layer by a row-wise kernel (same count, cheaper)
+        assert launches >= 6
     T, dWs, das = oracle_gat_epoch(g, H0, labels, Ws, As)
     for l in range(2):
         assert rel_err(ctx.download(l, "z"), T[f"z{l}"]) < RTOL, l
