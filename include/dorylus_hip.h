@@ -250,7 +250,8 @@ int dory_timing_reset(dory_ctx *ctx);
  * of every row's edges, so that an exchange in flight hides under the local-source part of EVERY row; "spmm_sweep_cus"
  * (before dory_graph_upload): workgroups per sweep and XCD of the gated sweeps, for contexts that share a device
  * (dory_comm_init_local); "local_timeout_ms"; "spmm_order" = 3 (before the upload): rows by median source id (experiment);
- * "gatmh_src_window_kb": the 8-head GAT's out-edge sweep layout on its own source window.  The timing family
+ * "gatmh_src_window_kb": the 8-head GAT's out-edge sweep layout on its own source window; "gat_reuse_nsum" (default 1): the GAT
+ * prototype's backward dA-weighted aggregation from the forward's unweighted neighbour sum (tensor "nsum") instead of a third sweep.  The timing family
  * "spmm_local_first" is the first launch of a two-launch aggregation when no exchange is in flight ("spmm_blk_force_split"). */
 int dory_set_option(dory_ctx *ctx, const char *key, int64_t value);
 int dory_get_option(dory_ctx *ctx, const char *key, int64_t *value);
