@@ -781,6 +781,13 @@ def extra_epoch(da, part, g, gnn, V, steps, warmup, what, dims=None, ghosts=Fals
     res = {"what": what, "ms_per_step": ms, "steps": steps, "warmup": warmup, "edges_per_s": edges / (ms * 1e-3),
            "spmm_variant": ctx.get_option("spmm_variant"),
            "kernel_ms_per_epoch": {k: round(v[0] / steps, 4) for k, v in fam.items() if v[1]}}
+    if gnn == "gat":
+        # edges_per_s counts the reference's SIX aggregations per epoch (2 forward + 2 x 2 backward); with gat_reuse_nsum the
+        # backward's dA-weighted one is a row-wise kernel on the forward's neighbour sum: four edge sweeps run
+        reuse = bool(ctx.get_option("gat_reuse_nsum"))
+        res["aggregations_counted_per_epoch"] = 6
+        res["edge_sweeps_per_epoch"] = 4 if reuse else 6
+        res["gat_reuse_nsum"] = reuse
     if gnn == "gcn" and dims is not None and fam["spmm"][1]:
         # roofline of this partition's aggregations (K1 row gather on partitions of this size: HBM / fabric bound):
         # compulsory bytes of the epoch's 2L-1 launches over their HIP-event time, and the gathered row bytes
