@@ -144,6 +144,37 @@ int wait_halo(dory_ctx *c) {
     return DORY_OK;
 }
 
+int gat_materialize(dory_ctx *c, uint32_t layer, int which) {
+    if (c->gnn != DORY_GAT || !c->prealloc) return DORY_OK;
+    if ((which & 1) && layer < c->gat_az_stale.size() && c->gat_az_stale[layer]) {
+        Tensor *az = find(c, layer, "az"), *azrow = find(c, layer, "azrow");
+        if (az && azrow) HIPCK(c, launch_expand_rows_to_edges(c->N, c->colPtr, azrow->d, az->d, c->compute));
+        c->gat_az_stale[layer] = 0;
+    }
+    if ((which & 2) && c->gat_A_stale_layer >= 0) {
+        Tensor *arow = find(c, (uint32_t)c->gat_A_stale_layer, "arow");
+        if (arow) HIPCK(c, launch_expand_rows_to_edges(c->N, c->colPtr, arow->d, c->cscVal, c->compute));
+        c->gat_A_stale_layer = -1;
+    }
+    if ((which & 4) && layer < c->gat_dA_stale.size() && c->gat_dA_stale[layer]) {
+        Tensor *dA = find(c, layer, "dA"), *drow = find(c, layer, "drow");
+        if (dA && drow) HIPCK(c, launch_expand_rows_to_edges(c->N, c->colPtr, drow->d, dA->d, c->compute));
+        c->gat_dA_stale[layer] = 0;
+    }
+    return DORY_OK;
+}
+static int gat_edge_tensor_hook(dory_ctx *c, uint32_t layer, const char *name, bool overwrite) {
+    if (c->gnn != DORY_GAT || !name) return DORY_OK;
+    const int which = !strcmp(name, "az") ? 1 : !strcmp(name, "A") ? 2 : !strcmp(name, "dA") ? 4 : 0;
+    if (!which) return DORY_OK;
+    if (!overwrite) return gat_materialize(c, layer, which);
+    // the caller's values replace the tensor: nothing of ours is pending any more, and the per-vertex copy no longer describes it
+    if (which == 1 && layer < c->gat_az_stale.size()) { c->gat_az_stale[layer] = 0; c->gat_azrow_valid[layer] = 0; }
+    if (which == 2) c->gat_A_stale_layer = -1;
+    if (which == 4 && layer < c->gat_dA_stale.size()) c->gat_dA_stale[layer] = 0;
+    return DORY_OK;
+}
+
 // Transform-first order for a GCN layer (opt-in, no reference counterpart): when a layer's input is wider than its
 // output, z_l = A (in_l W_l) gathers d[l+1]-wide rows instead of the d[l]-wide rows of (A in_l) W_l -- 128 instead of
 // 602 floats per edge on Reddit's layer 0, 41 instead of 128 on layer 1.  Backward: u_l = A^T g_l (d[l+1] wide),
@@ -228,6 +259,7 @@ int dory_create(int device, dory_ctx **out) {
     c->opt["spmm_blk_group"] = 32;   // K1b: lanes per row (slab = 4*group floats = 512 B)
     c->opt["spmm_blk_force_split"] = 0;   // testing: always launch local / ghost source blocks separately
     c->opt["halo_overlap"] = 1;      // let local-source blocks of the next SpMM run under the exchange
+    c->opt["gat_lazy_edge_tensors"] = 1;  // GAT prototype: az / A / dA (one value per destination) are written per edge only when read (download, raw pointer, K1's per-edge path)
     c->opt["gat_reuse_nsum"] = 1;         // GAT prototype: the backward's dA-weighted aggregation from the forward's neighbour sum (abi_stages.hip)
     c->opt["spmm_edge_split"] = 1;        // K1 on GCN partitions with ghosts: every row's local-source edges first (set before dory_graph_upload)
     c->opt["spmm_sweep_cus"] = 0;         // K1s / GAT sweeps: workgroups per sweep and XCD (0 = all CUs of an XCD); see dory_set_option
@@ -575,6 +607,11 @@ int dory_preallocate(dory_ctx *c) {
             mk(l, "arow", N, 1);   // per-destination value of "A"  (all edges of a column are equal)
             mk(l, "drow", N, 1);   // per-destination value of "dA"
         }
+        for (uint32_t l = 0; l < L; ++l) mk(l, "azrow", N, 1);  // per-destination value of "az"
+        c->gat_az_stale.assign(L, 0);
+        c->gat_dA_stale.assign(L, 0);
+        c->gat_azrow_valid.assign(L, 0);
+        c->gat_A_stale_layer = -1;
         for (uint32_t l = 0; l < L; ++l) mk(l, "nsum", N, d[l + 1]);   // unweighted neighbour sum of z (kept from the forward for the backward aggregation)
         mk(0, "ones", N, 1);
         c->gat_arow_valid.assign(L, 0);
@@ -707,6 +744,7 @@ int dory_tensor_info(dory_ctx *c, uint32_t layer, const char *name, uint64_t *ro
     CHECK_CTX(c);
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t) return fail(c, DORY_ERR_ARG, "no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    if (device_ptr) { int hrc = gat_edge_tensor_hook(c, layer, name, false); if (hrc) return hrc; }   // a raw pointer: the data behind it must be current
     if (rows) *rows = t->rows;
     if (cols) *cols = t->cols;
     if (ld) *ld = t->ld;
@@ -753,6 +791,7 @@ int dory_tensor_upload(dory_ctx *c, uint32_t layer, const char *name, const floa
     if (!strcmp(name, "A")) for (auto &f : c->gat_arow_valid) f = 0;          // caller-supplied edge weights: general path
     if (!strcmp(name, "dA") && layer < c->gat_drow_valid.size()) c->gat_drow_valid[layer] = 0;
     if ((!strcmp(name, "z") || !strcmp(name, "fg_z")) && layer < c->gat_nsum_valid.size()) c->gat_nsum_valid[layer] = 0;
+    { int hrc = gat_edge_tensor_hook(c, layer, name, true); if (hrc) return hrc; }
     return upload_dense(c, *t, host);
 }
 
@@ -761,6 +800,7 @@ int dory_tensor_download(dory_ctx *c, uint32_t layer, const char *name, float *h
     { int wrc = wait_halo(c); if (wrc) return wrc; }
     Tensor *t = name ? find(c, layer, name) : nullptr;
     if (!t || !host) return fail(c, DORY_ERR_ARG, "tensor_download: no tensor '%s' at layer %u", name ? name : "(null)", layer);
+    { int hrc = gat_edge_tensor_hook(c, layer, name, false); if (hrc) return hrc; }
     return download_dense(c, *t, host);
 }
 

@@ -98,6 +98,8 @@ int upload_array(dory_ctx *c, T **dst, const T *src, uint64_t n) {
 int wait_halo(dory_ctx *c);
 // in-process device transport: second half of a deferred exchange (abi_comm.hip); wait_halo and dory_sync run it
 int local_exchange_finish(dory_ctx *c);
+// GAT prototype, lazy per-edge tensors (ctx.hpp): bring az@layer (1), "A" (2), dA@layer (4) up to date before somebody reads them
+int gat_materialize(dory_ctx *c, uint32_t layer, int which);
 // transform-first order applies to this GCN layer (option, model shape, adjacency values): see abi_context.hip
 bool tf_layer(dory_ctx *c, uint32_t layer);
 bool tf_active(dory_ctx *c);   // = tf_layer(c, 0)

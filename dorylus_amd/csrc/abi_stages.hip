@@ -615,6 +615,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
                 return DORY_OK;
             }
         }
+        { int mrc = gat_materialize(c, fl, 2); if (mrc) return mrc; }   // (K1 reads the per-edge values)
         return spmm(c, true, c->cscVal, 2, *z, fgz, *ah, c->dims[layer], 0, fast ? arow->d : nullptr);
     }
     NEED(grad, fl, "grad");
@@ -631,6 +632,7 @@ int dory_aggregate(dory_ctx *c, uint32_t layer, int dir) {
         HIPCK(c, launch_row_axpy(aTg->d, nsum->d, drow->d, nullptr, c->N, aTg->ld, c->compute));
         return DORY_OK;
     }
+    { int mrc = gat_materialize(c, fl, 4); if (mrc) return mrc; }
     return spmm(c, true, dA->d, 0, *z, fgz, *aTg, c->dims[layer], 1, fast ? drow->d : nullptr);
 }
 
@@ -759,10 +761,16 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     NEED(az, fl, "az");
     if (dir == DORY_FORWARD) {  // edgNNForwardGAT (CPU_comm.cpp:190-203)
         NEED(arow, fl, "arow");
+        NEED(azrow, fl, "azrow");
         Timed t(c, "edge", c->compute);
-        HIPCK(c, launch_edge_forward_gat(c->N, F, c->colPtr, z->d, z->ld, a.d, az->d, c->cscVal, arow->d, c->compute));
+        const bool lazy = c->opt["gat_lazy_edge_tensors"] != 0;
+        HIPCK(c, launch_edge_forward_gat(c->N, F, c->colPtr, z->d, z->ld, a.d, lazy ? nullptr : az->d, lazy ? nullptr : c->cscVal, arow->d,
+                                         c->compute, azrow->d));
         for (auto &f : c->gat_arow_valid) f = 0;   // "A" now holds this layer's scores only
         c->gat_arow_valid[fl] = 1;
+        c->gat_azrow_valid[fl] = 1;
+        c->gat_az_stale[fl] = lazy ? 1 : 0;        // (lazy: the per-edge copies follow when somebody reads them, gat_materialize)
+        c->gat_A_stale_layer = lazy ? (int)fl : -1;
         return DORY_OK;
     }
     // edgNNBackwardGAT (CPU_comm.cpp:205-242)
@@ -778,7 +786,15 @@ int dory_apply_edge(dory_ctx *c, uint32_t layer, int dir) {
     float *partial = y + ((c->N + 63) & ~63u);
     const size_t pbytes = c->scratch_bytes - (size_t)(partial - c->scratch) * sizeof(float);
     Timed t(c, "edge", c->compute);
-    HIPCK(c, launch_edge_backward_gat(c->N, F, c->colPtr, grad->d, grad->ld, az->d, a.d, dA->d, cw->d, drow->d, c->compute));
+    {
+        Tensor *azrow = find(c, fl, "azrow");
+        const bool have_row = azrow && c->gat_azrow_valid[fl];
+        const bool lazy = c->opt["gat_lazy_edge_tensors"] != 0 && have_row;
+        if (!have_row) { int mrc = gat_materialize(c, fl, 1); if (mrc) return mrc; }   // (az comes from the caller, or is current already)
+        HIPCK(c, launch_edge_backward_gat(c->N, F, c->colPtr, grad->d, grad->ld, az->d, a.d, lazy ? nullptr : dA->d, cw->d, drow->d, c->compute,
+                                          have_row ? azrow->d : nullptr));
+        c->gat_dA_stale[fl] = lazy ? 1 : 0;
+    }
     c->gat_drow_valid[fl] = 1;
     // r = grad^T cw ; da = z^T (z r)   [= (z^T z) r^T, CPU_comm.cpp:232-236, without the F x F matrix]
     HIPCK(c, launch_colsum_w(c->N, F, grad->d, grad->ld, cw->d, partial, pbytes, r, c->compute));

@@ -167,6 +167,11 @@ struct dory_ctx {
                                                 // it), workgroups of the launch in flight that have left
     // GAT: per-destination edge factors written by dory_apply_edge are valid for these layers
     std::vector<char> gat_arow_valid, gat_drow_valid;
+    // GAT prototype, "gat_lazy_edge_tensors": the per-edge tensors az / A / dA hold one value per DESTINATION; the stages keep the
+    // per-vertex values (azrow / arow / drow) and write the per-edge copies only when somebody asks for them
+    std::vector<char> gat_azrow_valid;              // azrow@l describes az@l (false after a caller uploaded az)
+    std::vector<char> gat_az_stale, gat_dA_stale;   // per layer: az@l / dA@l are behind azrow@l / drow@l
+    int gat_A_stale_layer = -1;                     // "A" (= forwardAdj.values) is behind arow@this layer
     std::vector<char> gat_nsum_valid;    // GAT prototype: "nsum"@l holds the unweighted neighbour sum of the current z / fg_z (forward -> backward)
     bool gat_ones_set = false;           // "ones"@0 filled
     bool last_spmm_unit = false;         // the last spmm() gathered with unit weights and a per-row factor (K1s / K1b), not with per-edge values (K1)
@@ -380,11 +385,13 @@ hipError_t launch_row_axpy(float *out, const float *S, const float *rs, const fl
 // K5 GAT edge kernels
 hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,
                                    uint32_t ldz, const float *a, float *az, float *A,
-                                   float *arow /*N: the column's A value*/, hipStream_t s);
+                                   float *arow /*N: the column's A value*/, hipStream_t s,
+                                   float *azrow = nullptr /*N: the column's az value; az == A == nullptr: per-edge copies left to launch_expand_rows_to_edges*/);
+hipError_t launch_expand_rows_to_edges(uint32_t N, const uint64_t *colptr, const float *row, float *out, hipStream_t s);
 hipError_t launch_edge_backward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *grad,
                                     uint32_t ldg, const float *az, const float *a, float *dA,
                                     float *cw /*N: deg(v)*dLRelu_v*/, float *drow /*N: the column's dA value*/,
-                                    hipStream_t s);
+                                    hipStream_t s, const float *azrow = nullptr /*N: read instead of az; dA may then be nullptr*/);
 hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *r, float *y,
                          hipStream_t s);
 hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *w,

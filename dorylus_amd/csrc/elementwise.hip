@@ -351,7 +351,7 @@ hipError_t launch_pad_copy(float *dst, uint32_t ldd, const float *src, uint32_t 
 __global__ __launch_bounds__(256) void edge_forward_gat_kernel(uint32_t N, uint32_t F,
                                                                const uint64_t *colptr, const float *z,
                                                                uint32_t ldz, const float *a, float *az,
-                                                               float *A, float *arow) {
+                                                               float *A, float *arow, float *azrow) {
     const int lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
@@ -360,18 +360,36 @@ __global__ __launch_bounds__(256) void edge_forward_gat_kernel(uint32_t N, uint3
     for (uint32_t j = lane; j < F; j += 64) s = fmaf(zr[j], a[j], s);
     s = wave_sum(s);
     const float act = s > 0.f ? s : 0.01f * s;
-    for (uint64_t e = colptr[v] + lane; e < colptr[v + 1]; e += 64) {
-        az[e] = s;
-        A[e] = act;
+    if (az)      // (nullptr: the per-edge copies are written on demand, expand_rows_to_edges)
+        for (uint64_t e = colptr[v] + lane; e < colptr[v + 1]; e += 64) {
+            az[e] = s;
+            A[e] = act;
+        }
+    if (lane == 0) {
+        arow[v] = act;   // every edge of column v carries the same weight
+        if (azrow) azrow[v] = s;
     }
-    if (lane == 0) arow[v] = act;   // every edge of column v carries the same weight
+}
+
+// per-edge copy of a per-destination value: out[e] = row[dst(e)] for every in-edge of every local vertex
+__global__ __launch_bounds__(256) void expand_rows_to_edges_kernel(uint32_t N, const uint64_t *colptr, const float *row, float *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= N) return;
+    const float x = row[v];
+    for (uint64_t e = colptr[v] + lane; e < colptr[v + 1]; e += 64) out[e] = x;
+}
+hipError_t launch_expand_rows_to_edges(uint32_t N, const uint64_t *colptr, const float *row, float *out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_rows_to_edges_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, colptr, row, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_edge_forward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *z,
                                    uint32_t ldz, const float *a, float *az, float *A, float *arow,
-                                   hipStream_t s) {
+                                   hipStream_t s, float *azrow) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(edge_forward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, z, ldz, a, az, A, arow);
+    hipLaunchKernelGGL(edge_forward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, z, ldz, a, az, A, arow, azrow);
     return hipGetLastError();
 }
 
@@ -384,18 +402,19 @@ __global__ __launch_bounds__(256) void edge_backward_gat_kernel(uint32_t N, uint
                                                                 const uint64_t *colptr,
                                                                 const float *grad, uint32_t ldg,
                                                                 const float *az, const float *a,
-                                                                float *dA, float *cw, float *drow) {
+                                                                float *dA, float *cw, float *drow, const float *azrow) {
     const int lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
     const uint64_t e0 = colptr[v], e1 = colptr[v + 1];
     float sv = 0.f;
-    if (e1 > e0) sv = az[e0] > 0.f ? 1.f : 0.01f;
+    if (e1 > e0) sv = (azrow ? azrow[v] : az[e0]) > 0.f ? 1.f : 0.01f;
     const float *gr = grad + (size_t)v * ldg;
     float s = 0.f;
     for (uint32_t j = lane; j < F; j += 64) s = fmaf(gr[j] * sv, a[j], s);
     s = wave_sum(s);
-    for (uint64_t e = e0 + lane; e < e1; e += 64) dA[e] = s;
+    if (dA)
+        for (uint64_t e = e0 + lane; e < e1; e += 64) dA[e] = s;
     if (lane == 0) {
         cw[v] = (float)(e1 - e0) * sv;
         drow[v] = s;
@@ -404,10 +423,10 @@ __global__ __launch_bounds__(256) void edge_backward_gat_kernel(uint32_t N, uint
 
 hipError_t launch_edge_backward_gat(uint32_t N, uint32_t F, const uint64_t *colptr, const float *grad,
                                     uint32_t ldg, const float *az, const float *a, float *dA, float *cw,
-                                    float *drow, hipStream_t s) {
+                                    float *drow, hipStream_t s, const float *azrow) {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(edge_backward_gat_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, F, colptr, grad,
-                       ldg, az, a, dA, cw, drow);
+                       ldg, az, a, dA, cw, drow, azrow);
     return hipGetLastError();
 }
 

@@ -1258,3 +1258,47 @@ def test_gemm_does_not_read_operand_padding(da):
     assert_parity(dW, orc.sgemm(ah[1], g1, ta=True), what="dW@1")
     assert_parity(grad, orc.sgemm(g1, Ws[1], tb=True), what="grad@1")
     ctx.close()
+
+
+def test_gat_lazy_edge_tensors_are_the_eager_ones(da):
+    """GAT prototype, gat_lazy_edge_tensors (round 6): az / A / dA hold one value per DESTINATION, so the stages keep the
+    per-vertex values and write the per-edge tensors only when somebody reads them (download, raw pointer, K1's per-edge
+    path).  After the same epoch the tensors a caller can see are the eager run's, bit for bit -- through
+    dory_tensor_download and through the dory_tensor_info pointer -- and a caller's own "az" still drives the backward."""
+    import ctypes as C
+    import partition_oracle as po
+    from helpers import make_ctx, random_graph
+    V, dims = 300, [24, 16, 6]
+    s, d = random_graph(4, V, 2500)
+    g = po.preprocess(s, d, np.zeros(V, np.int64), 0, 1)
+    rng = np.random.default_rng(2)
+    H0 = rng.uniform(-1, 1, (V, dims[0])).astype(np.float32)
+    labels = rng.integers(0, dims[-1], V).astype(np.uint32)
+    Ws = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
+    As = [(rng.standard_normal((dims[i + 1], 1)) / 2).astype(np.float32) for i in range(2)]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    got = {}
+    for lazy in (0, 1):
+        for nb in (0, 8):                       # K1 (reads the per-edge values itself) and the blocked layouts (never do)
+            ctx = make_ctx(da, g, dims, V, gnn=da.GAT, options={"spmm_blk_nb": nb, "gat_lazy_edge_tensors": lazy})
+            ctx.upload(0, "h", H0)
+            ctx.labels_upload(labels)
+            for l in range(2):
+                ctx.weight_set(l, "w", Ws[l])
+                ctx.weight_set(l, "a_i", As[l])
+            da.NativeEngine(ctx).run(1)
+            out = {f"{nm}{l}": ctx.download(l, nm) for l in range(2) for nm in ("az", "dA", "ah", "aTg")}
+            out["A"] = ctx.download(0, "A")      # (= forwardAdj.values: the scores of the layer whose edge stage ran last)
+            rows, cols, ld, ptr = ctx.info(1, "az")
+            raw = np.empty(rows * max(ld, 1), np.float32)
+            ctx.sync()
+            assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), raw.nbytes, 2) == 0
+            out["az1_raw"] = raw
+            for k, v in out.items():
+                key = (nb, k)
+                if key in got:
+                    assert np.array_equal(got[key], v), (lazy, nb, k)
+                got[key] = v
+            ctx.close()
+    assert np.array_equal(got[(8, "az1_raw")][:got[(8, "az1")].size], got[(8, "az1")].ravel())
