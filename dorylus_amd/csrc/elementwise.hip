@@ -444,30 +444,61 @@ __global__ __launch_bounds__(256) void rowdot_kernel(uint32_t N, uint32_t F, con
 }
 
 // partial[b][j] = sum_{v in block b's rows} w[v] * X[v,j];  then out[j] = sum_b partial[b][j]
+// out[j] = sum_v w[v] * X[v, j]: column sums weighted per row (the a_i gradient of the GAT prototype, CPU_comm.cpp:232-236).
+// Round 6: float4 columns x row groups per workgroup (all 256 threads load, rows in flight in parallel) and a tree-free, fixed-order
+// second stage on 32 columns x 8 row groups per workgroup -- 80 + 43 us -> per call at Reddit size before (one thread per column
+// walking its block's rows, then one thread per column walking 1 024 partials).  Sums are formed in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void colsum_w_kernel(uint32_t N, uint32_t F, const float *X, uint32_t ld,
                                                        const float *w, float *partial, uint32_t rows_per_block) {
+    __shared__ float4 red[256];
     const uint32_t r0 = blockIdx.x * rows_per_block;
     const uint32_t r1 = min(N, r0 + rows_per_block);
-    for (uint32_t j = threadIdx.x; j < F; j += 256) {
-        float s = 0.f;
-        for (uint32_t v = r0; v < r1; ++v) s = fmaf(w[v], X[(size_t)v * ld + j], s);
-        partial[(size_t)blockIdx.x * F + j] = s;
+    const uint32_t F4 = (F + 3) >> 2;                 // float4 columns (rows are padded to 32 floats: the last one reads padding zeros)
+    const uint32_t CW = min(F4, 256u);                // columns handled per pass
+    const uint32_t RG = 256u / CW;                    // row groups
+    const uint32_t c = threadIdx.x % CW, rg = threadIdx.x / CW;
+    for (uint32_t c0 = 0; c0 < F4; c0 += CW) {
+        const uint32_t col = c0 + c;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < F4 && rg < RG)
+            for (uint32_t v = r0 + rg; v < r1; v += RG) {
+                const float wv = w[v];
+                float4 x;
+                if ((ld & 3u) == 0) {
+                    x = *reinterpret_cast<const float4 *>(X + (size_t)v * ld + 4 * col);
+                } else {                               // (one-column tensors keep ld = 1: element loads, zeros past F)
+                    const float *xr = X + (size_t)v * ld + 4 * col;
+                    x = make_float4(xr[0], 4 * col + 1 < F ? xr[1] : 0.f, 4 * col + 2 < F ? xr[2] : 0.f, 4 * col + 3 < F ? xr[3] : 0.f);
+                }
+                s.x = fmaf(wv, x.x, s.x); s.y = fmaf(wv, x.y, s.y); s.z = fmaf(wv, x.z, s.z); s.w = fmaf(wv, x.w, s.w);
+            }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rg == 0 && col < F4) {
+            for (uint32_t k = 1; k < RG; ++k) {       // row groups in order
+                const float4 t = red[k * CW + c];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            float *p = partial + (size_t)blockIdx.x * F + 4 * col;
+            const float r[4] = {s.x, s.y, s.z, s.w};
+            for (uint32_t q = 0; q < 4 && 4 * col + q < F; ++q) p[q] = r[q];
+        }
+        __syncthreads();
     }
 }
-__global__ void colsum_final_kernel(uint32_t F, const float *partial, uint32_t nb, float *out) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= F) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(uint32_t F, const float *partial, uint32_t nb, float *out) {
+    __shared__ float red[256];
+    const uint32_t c = threadIdx.x & 31u, rg = threadIdx.x >> 5;      // 32 columns x 8 groups of partials
+    const uint32_t j = blockIdx.x * 32u + c;
     float s = 0.f;
-    uint32_t b = 0;
-    for (; b + 8 <= nb; b += 8) {   // eight loads in flight, adds in block order
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * F + j];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+    if (j < F)
+        for (uint32_t b = rg; b < nb; b += 8) s += partial[(size_t)b * F + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && j < F) {
+        for (uint32_t k = 1; k < 8; ++k) s += red[k * 32 + c];
+        out[j] = s;
     }
-    for (; b < nb; ++b) s += partial[(size_t)b * F + j];
-    out[j] = s;
 }
 
 hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *r, float *y,
@@ -481,13 +512,13 @@ hipError_t launch_rowdot(uint32_t N, uint32_t F, const float *X, uint32_t ld, co
 hipError_t launch_colsum_w(uint32_t N, uint32_t F, const float *X, uint32_t ld, const float *w,
                            float *partial, size_t partial_bytes, float *out, hipStream_t s) {
     if (F == 0) return hipSuccess;
-    uint32_t nb = 1024;
+    uint32_t nb = 512;
     while (nb > 1 && (nb > N / 64 || (size_t)nb * F * sizeof(float) > partial_bytes)) nb >>= 1;   // >= 64 rows per block
     const uint32_t rpb = (N + nb - 1) / nb > 0 ? (N + nb - 1) / nb : 1;
     nb = (N + rpb - 1) / rpb;
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(colsum_w_kernel, dim3(nb), dim3(256), 0, s, N, F, X, ld, w, partial, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 255) / 256), dim3(256), 0, s, F, partial, nb, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(256), 0, s, F, partial, nb, out);
     return hipGetLastError();
 }
 
